@@ -1,0 +1,284 @@
+/* vec.c — array-of-environments drivers around the scalar restatements.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * This is the loop a caller of the reference would write (one env object per
+ * environment, `for env in envs { env.step(a) }`), with SoA in/out buffers so the
+ * results compare 1:1 with the HIP engine's.  Optional OpenMP threading is an index
+ * shard of that loop (used for the "all host cores" CPU baseline).
+ *
+ * State blob layout ([col][n] 4-byte words; integer columns are bit patterns):
+ *   cartpole        : x, x_dot, theta, theta_dot, steps_since_reset(u32), sbt(i32, -1=None), episode(u32)
+ *   mountaincar(+c) : position, velocity, episode(u32)
+ *   lunarlander     : ora_lunarlander_state_floats() columns (see lunar_lander.c) + episode(u32)
+ */
+#include "oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+struct ora_vec {
+    ora_vec_config cfg;
+    ora_cartpole *cp;
+    ora_mountaincar *mc;
+    ora_mountaincar_cont *mcc;
+    ora_lunarlander **ll;
+    uint32_t *episode;   /* number of resets done so far (RNG counter word 2) */
+    uint32_t *ll_step;   /* lunar lander: steps since reset (RNG slot) */
+    const float *disp_override;
+};
+
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+ora_vec *ora_vec_new(const ora_vec_config *cfg, int *status) {
+    ora_vec *v = (ora_vec *)calloc(1, sizeof(*v));
+    size_t n = (size_t)cfg->n_envs;
+    v->cfg = *cfg;
+    v->episode = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    int st = ORA_OK;
+    switch (cfg->kind) {
+    case 0:
+        v->cp = (ora_cartpole *)malloc((n ? n : 1) * sizeof(ora_cartpole));
+        for (size_t i = 0; i < n; ++i) ora_cartpole_new(&v->cp[i], cfg->sutton_barto_reward, cfg->is_euler);
+        break;
+    case 1:
+        v->mc = (ora_mountaincar *)malloc((n ? n : 1) * sizeof(ora_mountaincar));
+        for (size_t i = 0; i < n; ++i) ora_mountaincar_new(&v->mc[i], cfg->goal_velocity);
+        break;
+    case 2:
+        v->mcc = (ora_mountaincar_cont *)malloc((n ? n : 1) * sizeof(ora_mountaincar_cont));
+        for (size_t i = 0; i < n; ++i) ora_mountaincar_cont_new(&v->mcc[i], cfg->goal_velocity);
+        break;
+    case 3:
+        v->ll = (ora_lunarlander **)calloc(n ? n : 1, sizeof(ora_lunarlander *));
+        v->ll_step = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+        for (size_t i = 0; i < n && st == ORA_OK; ++i)
+            v->ll[i] = ora_lunarlander_new(cfg->gravity, cfg->enable_wind, cfg->wind_power,
+                                           cfg->turbulence_power, &st);
+        break;
+    default:
+        st = ORA_BAD_CONFIG;
+    }
+    if (status) *status = st;
+    if (st != ORA_OK) { ora_vec_free(v); return NULL; }
+    return v;
+}
+
+void ora_vec_free(ora_vec *v) {
+    if (!v) return;
+    if (v->ll) {
+        for (size_t i = 0; i < (size_t)v->cfg.n_envs; ++i)
+            if (v->ll[i]) ora_lunarlander_free(v->ll[i]);
+        free(v->ll);
+    }
+    free(v->cp); free(v->mc); free(v->mcc); free(v->episode); free(v->ll_step);
+    free(v);
+}
+
+int ora_vec_obs_dim(const ora_vec *v) {
+    static const int d[4] = {4, 2, 2, 8};
+    return d[v->cfg.kind];
+}
+
+static void draw(const ora_vec *v, size_t i, uint32_t slot, uint32_t w[4]) {
+    uint64_t id = v->cfg.env_id_base + (uint64_t)i;
+    uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), v->episode[i], slot};
+    uint32_t key[2] = {(uint32_t)v->cfg.seed, (uint32_t)(v->cfg.seed >> 32)};
+    ora_philox4x32_10(ctr, key, w);
+}
+
+static void ll_dispersion(const ora_vec *v, size_t i, float d[2]) {
+    size_t n = (size_t)v->cfg.n_envs;
+    if (v->disp_override) { d[0] = v->disp_override[i]; d[1] = v->disp_override[n + i]; return; }
+    uint32_t w[4];
+    draw(v, i, ORA_SLOT_STEP_BASE + v->ll_step[i], w);
+    /* rng.random_range(-1.0..1.0): value0_1 * scale + low  (lunar_lander.rs:973-974) */
+    d[0] = ora_u23(w[0]) * 2.0f + -1.0f;
+    d[1] = ora_u23(w[1]) * 2.0f + -1.0f;
+}
+
+static int reset_one(ora_vec *v, size_t i, float *obs_soa) {
+    size_t n = (size_t)v->cfg.n_envs;
+    uint32_t w[16];
+    int st = ORA_OK;
+    switch (v->cfg.kind) {
+    case 0: {
+        draw(v, i, ORA_SLOT_RESET0, w);
+        draw(v, i, ORA_SLOT_RESET1, w + 4);
+        double u[4];
+        for (int k = 0; k < 4; ++k) u[k] = ora_u53(w[2 * k], w[2 * k + 1]);
+        ora_cartpole_reset(&v->cp[i], u);
+        if (obs_soa) for (int k = 0; k < 4; ++k) obs_soa[(size_t)k * n + i] = v->cp[i].state[k];
+        break;
+    }
+    case 1:
+        draw(v, i, ORA_SLOT_RESET0, w);
+        ora_mountaincar_reset(&v->mc[i], ora_u53(w[0], w[1]));
+        if (obs_soa) { obs_soa[i] = v->mc[i].state[0]; obs_soa[n + i] = v->mc[i].state[1]; }
+        break;
+    case 2:
+        draw(v, i, ORA_SLOT_RESET0, w);
+        ora_mountaincar_cont_reset(&v->mcc[i], ora_u53(w[0], w[1]));
+        if (obs_soa) { obs_soa[i] = v->mcc[i].state[0]; obs_soa[n + i] = v->mcc[i].state[1]; }
+        break;
+    case 3: {
+        for (uint32_t s = 0; s < 4; ++s) draw(v, i, ORA_SLOT_RESET0 + s, w + 4 * s);
+        float uh[12], uf[2], d0[2], obs[8];
+        for (int k = 0; k < 12; ++k) uh[k] = ora_u23(w[k]);
+        uf[0] = ora_u23(w[12]);
+        uf[1] = ora_u23(w[13]);
+        /* rng.random_range(-9999..9999) (lunar_lander.rs:855-856): uniform over 19998 integers */
+        int32_t wi = -9999 + (int32_t)(((uint64_t)w[14] * 19998u) >> 32);
+        int32_t ti = -9999 + (int32_t)(((uint64_t)w[15] * 19998u) >> 32);
+        v->ll_step[i] = 0;
+        ll_dispersion(v, i, d0);
+        st = ora_lunarlander_reset(v->ll[i], uh, uf, wi, ti, d0, obs);
+        v->ll_step[i] = 1;
+        if (obs_soa) for (int k = 0; k < 8; ++k) obs_soa[(size_t)k * n + i] = obs[k];
+        break;
+    }
+    }
+    v->episode[i] += 1;
+    return st;
+}
+
+int ora_vec_reset(ora_vec *v, const uint8_t *mask, float *obs_soa, int nthreads) {
+    long n = (long)v->cfg.n_envs;
+    int err = ORA_OK;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1)
+    for (long i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        int st = reset_one(v, (size_t)i, obs_soa);
+        if (st != ORA_OK) {
+#pragma omp atomic write
+            err = st;
+        }
+    }
+    return err;
+}
+
+int ora_vec_step(ora_vec *v, const void *actions, float *obs_soa, float *reward, uint8_t *done,
+                 uint8_t *trunc, int nthreads) {
+    long n = (long)v->cfg.n_envs;
+    const uint32_t *au = (const uint32_t *)actions;
+    const float *af = (const float *)actions;
+    int kind = v->cfg.kind;
+    int err = ORA_OK;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1)
+    for (long i = 0; i < n; ++i) {
+        ora_stepinfo si = {0.0f, 0, 0};
+        int st = ORA_OK;
+        switch (kind) {
+        case 0:
+            st = ora_cartpole_step(&v->cp[i], au[i], &si);
+            if (obs_soa && st == ORA_OK)
+                for (int k = 0; k < 4; ++k) obs_soa[(size_t)k * n + i] = v->cp[i].state[k];
+            break;
+        case 1:
+            st = ora_mountaincar_step(&v->mc[i], au[i], &si);
+            if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mc[i].state[0]; obs_soa[n + i] = v->mc[i].state[1]; }
+            break;
+        case 2:
+            st = ora_mountaincar_cont_step(&v->mcc[i], af[i], &si);
+            if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mcc[i].state[0]; obs_soa[n + i] = v->mcc[i].state[1]; }
+            break;
+        case 3: {
+            float d[2], obs[8];
+            ll_dispersion(v, (size_t)i, d);
+            st = ora_lunarlander_step(v->ll[i], au[i], d, obs, &si);
+            v->ll_step[i] += 1;
+            if (obs_soa && st == ORA_OK) for (int k = 0; k < 8; ++k) obs_soa[(size_t)k * n + i] = obs[k];
+            break;
+        }
+        }
+        if (st != ORA_OK) {
+#pragma omp atomic write
+            err = st;
+            continue;
+        }
+        if (reward) reward[i] = si.reward;
+        if (done) done[i] = si.done;
+        if (trunc) trunc[i] = si.truncated;
+    }
+    return err;
+}
+
+int ora_vec_state_cols(const ora_vec *v) {
+    switch (v->cfg.kind) {
+    case 0: return 7;
+    case 1: case 2: return 3;
+    default: return ora_lunarlander_state_floats() + 2;
+    }
+}
+
+void ora_vec_get_state(const ora_vec *v, float *soa) {
+    size_t n = (size_t)v->cfg.n_envs;
+    for (size_t i = 0; i < n; ++i) {
+        switch (v->cfg.kind) {
+        case 0: {
+            const ora_cartpole *e = &v->cp[i];
+            for (int k = 0; k < 4; ++k) soa[(size_t)k * n + i] = e->state[k];
+            uint64_t s = e->steps_since_reset > 0xFFFFFFu ? 0xFFFFFFu : e->steps_since_reset;
+            soa[4 * n + i] = u2f((uint32_t)s);
+            int32_t sbt = e->sbt_is_some ? (int32_t)(e->sbt > 254 ? 254 : e->sbt) : -1;
+            soa[5 * n + i] = u2f((uint32_t)sbt);
+            soa[6 * n + i] = u2f(v->episode[i]);
+            break;
+        }
+        case 1:
+            soa[i] = v->mc[i].state[0]; soa[n + i] = v->mc[i].state[1]; soa[2 * n + i] = u2f(v->episode[i]);
+            break;
+        case 2:
+            soa[i] = v->mcc[i].state[0]; soa[n + i] = v->mcc[i].state[1]; soa[2 * n + i] = u2f(v->episode[i]);
+            break;
+        case 3: {
+            int nf = ora_lunarlander_state_floats();
+            float *tmp = (float *)malloc((size_t)nf * sizeof(float));
+            ora_lunarlander_export(v->ll[i], tmp);
+            for (int k = 0; k < nf; ++k) soa[(size_t)k * n + i] = tmp[k];
+            soa[(size_t)nf * n + i] = u2f(v->ll_step[i]);
+            soa[(size_t)(nf + 1) * n + i] = u2f(v->episode[i]);
+            free(tmp);
+            break;
+        }
+        }
+    }
+}
+
+void ora_vec_set_state(ora_vec *v, const float *soa) {
+    size_t n = (size_t)v->cfg.n_envs;
+    for (size_t i = 0; i < n; ++i) {
+        switch (v->cfg.kind) {
+        case 0: {
+            ora_cartpole *e = &v->cp[i];
+            for (int k = 0; k < 4; ++k) e->state[k] = soa[(size_t)k * n + i];
+            e->steps_since_reset = f2u(soa[4 * n + i]);
+            int32_t sbt = (int32_t)f2u(soa[5 * n + i]);
+            e->sbt_is_some = sbt >= 0;
+            e->sbt = sbt >= 0 ? (uint64_t)sbt : 0;
+            v->episode[i] = f2u(soa[6 * n + i]);
+            break;
+        }
+        case 1:
+            v->mc[i].state[0] = soa[i]; v->mc[i].state[1] = soa[n + i]; v->episode[i] = f2u(soa[2 * n + i]);
+            break;
+        case 2:
+            v->mcc[i].state[0] = soa[i]; v->mcc[i].state[1] = soa[n + i]; v->episode[i] = f2u(soa[2 * n + i]);
+            break;
+        case 3: {
+            int nf = ora_lunarlander_state_floats();
+            float *tmp = (float *)malloc((size_t)nf * sizeof(float));
+            for (int k = 0; k < nf; ++k) tmp[k] = soa[(size_t)k * n + i];
+            ora_lunarlander_import(v->ll[i], tmp);
+            v->ll_step[i] = f2u(soa[(size_t)nf * n + i]);
+            v->episode[i] = f2u(soa[(size_t)(nf + 1) * n + i]);
+            free(tmp);
+            break;
+        }
+        }
+    }
+}
+
+void ora_vec_set_dispersion(ora_vec *v, const float *disp_soa) { v->disp_override = disp_soa; }
