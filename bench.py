@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched step()/reset() hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE).
+A "step" is one pass of the hot path over one batch: every environment of the rank's shard
+advances by one Gym::step, and every episode that finished is reset (so the population stays
+in-distribution).  Default workload = BASELINE.json configs[1]: CartPole-v1, 1 048 576 envs per
+GPU (weak scaling: rank r owns global env ids [r*n, (r+1)*n), no data-path collective).
+W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize()
+on both sides; MAX over ranks; rank 0 prints ONE JSON line.
+
+Inputs are synthetic and already resident in HBM when the timed region starts: states come from
+the engine's own reset, actions from a ring of 16 pre-generated uniform columns.
+
+Besides the contract fields the line carries
+  roofline     — dominant kernel (the step kernel): algorithmic bytes per launch / average launch
+                 duration from HIP events on the launch stream over the timed region, vs 8 TB/s.
+  cpu_baseline — the CPU oracle (C restatement of the Rust reference; the reference itself cannot
+                 be built here) timed on this box's host cores on a bounded sample, rank 0, N=1 only.
+  extra        — the other BASELINE configs measured after the timed region (not the headline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RING = 16  # pre-generated action columns (actions are not cache-resident constants)
+HBM_PEAK = 8.0e12
+ALG_BYTES = {"cartpole": 50, "mountain_car": 26, "mountain_car_cont": 26}  # SURVEY §8d, DESIGN.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cartpole",
+                    choices=["cartpole", "mountain_car", "mountain_car_cont", "lunar_lander", "mixed"])
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: BASELINE size)")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--reset", default="fused", choices=["fused", "separate"],
+                    help="fused: auto-reset inside the step kernel; separate: step + mgym_reset_done launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    return ap.parse_args()
+
+
+class Stepper:
+    """One env family on this rank: device buffers, an action ring and a (graph-captured) step."""
+
+    def __init__(self, mg, torch, kind_name, n, device, seed, base, stream, reset_mode, launch):
+        kinds = {"cartpole": (mg.CARTPOLE, 2), "mountain_car": (mg.MOUNTAINCAR, 3),
+                 "mountain_car_cont": (mg.MOUNTAINCAR_CONT, 0), "lunar_lander": (mg.LUNARLANDER, 4)}
+        kind, nact = kinds[kind_name]
+        self.name, self.n, self.reset_mode, self.launch = kind_name, n, reset_mode, launch
+        extra = dict(enable_wind=True) if kind_name == "lunar_lander" else {}
+        self.env = mg.VecEnv(kind, n, device=device, seed=seed, env_id_base=base, auto_reset=(reset_mode == "fused"),
+                             stream=stream.cuda_stream, **extra)
+        g = torch.Generator(device=f"cuda:{device}")
+        g.manual_seed(seed & 0x7FFFFFFF)
+        if nact:
+            self.actions = torch.randint(0, nact, (RING, n), generator=g, device=f"cuda:{device}", dtype=torch.int32)
+        else:
+            self.actions = torch.rand((RING, n), generator=g, device=f"cuda:{device}", dtype=torch.float32) * 2 - 1
+        self.reward = torch.empty(n, device=f"cuda:{device}", dtype=torch.float32)
+        self.done = torch.zeros(n, device=f"cuda:{device}", dtype=torch.uint8)
+        self.trunc = torch.zeros(n, device=f"cuda:{device}", dtype=torch.uint8)
+        self.env.reset_device(None, None)
+        self.graph = None
+        self.t = 0
+
+    def one(self, k):
+        a = self.actions[k % RING]
+        # obs_out = NULL: the policy reads the engine-owned observation (mgym_observation), zero-copy
+        self.env.step_device(a, None, self.reward, self.done, self.trunc)
+        if self.reset_mode == "separate":
+            self.env.reset_done_device(self.done, self.trunc, None)
+
+    def build_graph(self):
+        self.graph = self.env.graph_capture(lambda: [self.one(k) for k in range(RING)])
+
+    def run(self, steps):
+        """issue exactly `steps` steps on the stream (graph replays of RING steps + eager remainder)"""
+        if self.launch == "graph" and self.graph is None and steps >= RING:
+            self.build_graph()
+        full = steps // RING if self.graph is not None else 0
+        for _ in range(full):
+            self.env.graph_launch(self.graph)
+        for k in range(steps - full * RING):
+            self.one(self.t + k)
+        self.t += steps - full * RING
+
+    def close(self):
+        if self.graph is not None:
+            self.env.graph_destroy(self.graph)
+        self.env.close()
+
+
+def host_cores():
+    """CPU share actually available to this process (affinity mask, then the cgroup quota)."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    c = min(c, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    c = min(c, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return max(1, min(c, int(os.environ.get("MGYM_BENCH_CORES", "16"))))  # a 1-GPU box has a 16-CPU share
+
+
+def cpu_baseline(workload, n, seed):
+    """The oracle on this box's host cores: `for env in envs { env.step(a) }` over a bounded sample."""
+    import numpy as np
+
+    from oracle import oracle as ora  # test infrastructure; timed here as the reported CPU baseline
+
+    kinds = {"cartpole": (ora.CARTPOLE, 2), "mountain_car": (ora.MOUNTAINCAR, 3), "mountain_car_cont": (ora.MOUNTAINCAR_CONT, 0)}
+    kind, nact = kinds[workload]
+    cores = host_cores()
+    rng = np.random.default_rng(0)
+    acts = [(rng.integers(0, nact, n).astype(np.uint32) if nact else rng.uniform(-1, 1, n).astype(np.float32))
+            for _ in range(4)]
+    out = {}
+    for label, threads, budget in (("1core", 1, 4.0), ("allcores", cores, 8.0)):
+        env = ora.OracleVec(kind, n, seed=seed)
+        env.reset(nthreads=threads)
+        bufs = (np.zeros((env.obs_dim, n), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            _, _, done, trunc = env.step(acts[steps % 4], nthreads=threads, out=bufs)
+            env.reset(mask=done | trunc, nthreads=threads)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget or steps >= 2000:
+                break
+        out[label] = (n * steps / el, steps, el)
+    v, steps, el = out["allcores"]
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{workload} {n} envs x {steps} steps (step + masked reset), {el:.1f} s, OpenMP index shards over {cores} threads; "
+                      f"oracle = C restatement of the Rust reference (cargo/rustc absent: reference unbuildable)",
+            "value_1core": out["1core"][0]}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+        args.gpus = world
+
+    import torch
+
+    import modurl_gym_amd as mg
+
+    if not torch.cuda.is_available() or mg.device_count() == 0:
+        print("bench.py: no MI355X visible — the engine has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    stream = torch.cuda.Stream(device=local_rank)
+    n_default = {"cartpole": 1 << 20, "mountain_car": 1 << 20, "mountain_car_cont": 1 << 20, "lunar_lander": 1 << 18,
+                 "mixed": 1 << 20}
+    n = args.envs or n_default[args.workload]
+    if args.workload == "mixed":
+        pop = mg.mixed_population(n)
+    else:
+        pop = {args.workload: n}
+    steppers, base = [], 0
+    for name, cnt in pop.items():
+        # global env ids: family blocks are laid out [family][rank][local index]
+        steppers.append(Stepper(mg, torch, name, cnt, local_rank, args.seed, base + rank * cnt, stream, args.reset, args.launch))
+        base += world * cnt
+    lead = steppers[0]
+
+    def run(steps):
+        for s in steppers:
+            s.run(steps)
+
+    run(args.warmup)
+    for s in steppers:
+        s.env.sync()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    lead.env.timer_start()            # hipEvent on the launch stream
+    t0 = time.perf_counter()
+    run(args.steps)                   # EXACTLY K steps
+    ev_ms = lead.env.timer_stop()     # second hipEvent + hipEventSynchronize
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+    for s in steppers:
+        s.env.sync()                  # surfaces any sticky device-side error
+
+    total_envs = sum(pop.values()) * world
+    value = total_envs * args.steps / elapsed
+    result = {
+        "metric": "env-steps/sec (whole node), CartPole 1M envs, at 1/2/4/8 MI355X",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"cartpole": "CartPole-v1, 1048576 envs per GPU, f32 SoA (BASELINE configs[1])",
+                                "mixed": "Mixed CartPole+MountainCar+LunarLander, 1048576 envs per GPU (BASELINE configs[4] per-GPU load)"}
+                   .get(args.workload, args.workload),
+                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": f"{args.launch} (hipGraph of {RING} steps)" if args.launch == "graph" else "eager",
+                   "reset": "fused auto-reset in the step kernel" if args.reset == "fused" else "separate mgym_reset_done launch per step",
+                   "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING},
+    }
+    if args.workload in ALG_BYTES:
+        # dominant kernel = the step kernel; with --reset fused the timed region is K launches of it
+        # (graph-replayed), so its average launch duration is event_time / K (includes the ~1.5 us
+        # inter-kernel boundary: conservative against rocprof's pure kernel duration)
+        alg = ALG_BYTES[args.workload] * n
+        dur = ev_ms * 1e-3 / args.steps
+        result["roofline"] = {"bound": "hbm", "achieved": alg / dur / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                              "frac": alg / dur / HBM_PEAK, "traffic": None,
+                              "kernel": f"{args.workload}_step_kernel<4>", "alg_bytes_per_launch": alg,
+                              "avg_launch_us": dur * 1e6,
+                              "note": "algorithmic bytes/env-step x envs per launch / HIP-event time per launch; at 1Mi envs the working set "
+                                      "(~50 MB) is Infinity-Cache resident, see DESIGN.md for the >256 MiB run"}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(f"{args.workload}:{n}")
+                if rec:
+                    result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    result["roofline"]["traffic_source"] = rec.get("source")
+            except Exception:
+                pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ALG_BYTES:
+        result["cpu_baseline"] = cpu_baseline(args.workload, n, args.seed)
+
+    for s in steppers:
+        s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+/* mgym.h — C ABI of libmgym: the MI355X (gfx950) batched environment-step engine.
+ *
+ * This is the drop-in boundary for the hot path of ModuRL/ModuRL_Gym: the bodies of
+ * `impl Gym for CartPoleV1 / MountainCarV0 / LunarLanderV3` — reset() and step() —
+ * re-expressed as struct-of-arrays HIP kernels over n_envs independent environments.
+ * Plain C: opaque handle, raw device pointers, sizes and status codes; no C++ or
+ * PyTorch types.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repo).  A Rust `Gym` shim / cgo / ctypes stub binds
+ * exactly these symbols.
+ *
+ * Conventions
+ *  - All `*_out` / `actions` / `mask` / `blob` pointers are DEVICE pointers on the
+ *    env's HIP device.  The engine owns only its internal SoA state; callers own
+ *    every buffer they pass.  No allocation or synchronisation happens inside
+ *    mgym_reset/mgym_step/mgym_reset_done (they are hipGraph-capturable).
+ *  - Observations are SoA: obs_out[k * n_envs + i] is component k of env i
+ *    (reference: rank-1 f32 tensor of 4 / 2 / 8 per env — cartpole.rs:285-290,
+ *    mountain_car.rs:315, lunar_lander.rs:1112-1123).
+ *  - Discrete actions are uint32_t[n_envs] (reference: rank-0 u32 tensor,
+ *    cartpole.rs:257,377); MountainCarContinuous takes float[n_envs].
+ *  - reward f32, done/truncated uint8 (StepInfo, cartpole.rs:300-305).
+ *  - Episode semantics are the reference's: NO auto-reset; stepping a finished env
+ *    keeps integrating (cartpole.rs:330-346).  MGYM_FLAG_AUTO_RESET opts into a fused
+ *    same-step reset (a superset feature, off by default).
+ *  - Where the reference panics (assert!/expect) the engine returns a status code;
+ *    errors detected on the device (invalid action) are sticky and reported by the
+ *    next mgym_sync().
+ *  - One handle = one device + one stream; calls on one handle are not thread-safe,
+ *    different handles are independent (reference: &mut self, single-threaded).
+ */
+#ifndef MGYM_H
+#define MGYM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGYM_ABI_VERSION 1
+
+typedef struct mgym_env mgym_env;
+
+typedef enum mgym_status {
+    MGYM_OK = 0,
+    MGYM_ERR_INVALID_ACTION = 1, /* assert!(action_space.contains(&action)): cartpole.rs:252, mountain_car.rs:294 */
+    MGYM_ERR_NOT_RESET = 2,      /* assert!(self.lander.is_some(), "You forgot to call reset()"): lunar_lander.rs:920 */
+    MGYM_ERR_BAD_CONFIG = 3,     /* assert!(-12.0 < gravity && gravity < 0.0): lunar_lander.rs:292-296 */
+    MGYM_ERR_HIP = 4,            /* HIP runtime failure (reference: candle_core::Error from tensor ops) */
+    MGYM_ERR_BAD_ARG = 5,        /* null/misaligned pointer, wrong kind */
+    MGYM_ERR_NO_DEVICE = 6       /* no gfx950 device / HIP runtime unusable: the engine has no CPU fallback */
+} mgym_status;
+
+typedef enum mgym_kind {
+    MGYM_CARTPOLE = 0,         /* CartPoleV1      — src/classic_control/cartpole.rs */
+    MGYM_MOUNTAINCAR = 1,      /* MountainCarV0   — src/classic_control/mountain_car.rs */
+    MGYM_MOUNTAINCAR_CONT = 2, /* MountainCarContinuous-v0 — NOT in the reference (parity unpinned) */
+    MGYM_LUNARLANDER = 3       /* LunarLanderV3   — src/box_2d/lunar_lander.rs */
+} mgym_kind;
+
+enum {
+    MGYM_FLAG_AUTO_RESET = 1u /* fused same-step reset of finished envs inside mgym_step (superset; default off) */
+};
+
+/* Builder arguments of the three reference constructors, plus batching/sharding fields.
+ *   CartPoleV1::builder():  sutton_barto_reward=false, is_euler=true      (cartpole.rs:36-44)
+ *   MountainCarV0::builder(): goal_velocity=0.0                           (mountain_car.rs:27-34)
+ *   LunarLanderV3::builder(): gravity=-10, enable_wind=false, wind_power=15,
+ *                             turbulence_power=1.5, seed                  (lunar_lander.rs:280-291)
+ * `device` is the HIP ordinal (reference: candle Device).  `env_id_base` is the global index
+ * of this handle's env 0: per-env random streams are keyed by (seed, env_id_base + i), so
+ * results do not depend on how a population is sharded over GPUs. */
+typedef struct mgym_config {
+    uint32_t struct_size; /* = sizeof(mgym_config) */
+    int32_t kind;         /* mgym_kind */
+    int32_t device;
+    uint32_t flags;
+    uint64_t n_envs;
+    uint64_t env_id_base;
+    uint64_t seed;
+    int32_t sutton_barto_reward;
+    int32_t is_euler;
+    float goal_velocity;
+    float gravity;
+    int32_t enable_wind;
+    float wind_power;
+    float turbulence_power;
+    uint32_t reserved;
+} mgym_config;
+
+/* Space metadata (reference: observation_space()/action_space(), cartpole.rs:58-69,350-356;
+ * mountain_car.rs:42-48; lunar_lander.rs:1169-1200). */
+typedef struct mgym_spec {
+    int32_t obs_dim;
+    int32_t n_actions;      /* Discrete(n); 0 for a continuous (Box) action space */
+    int32_t action_is_float;
+    int32_t state_cols;     /* columns of the get/set_state blob */
+    float obs_low[8], obs_high[8];
+    float action_low, action_high; /* continuous only */
+} mgym_spec;
+
+int mgym_abi_version(void);
+
+/* Fill `cfg` with the reference builder defaults for `kind` (n_envs = 1, device 0, seed 0). */
+int mgym_default_config(int kind, mgym_config *cfg);
+
+/* Replaces {CartPoleV1,MountainCarV0,LunarLanderV3}::builder()...build()
+ * (cartpole.rs:37-96, mountain_car.rs:27-69, lunar_lander.rs:281-352).
+ * Initial state as constructed by the reference: zeros; CartPole steps_beyond_terminated=Some(0). */
+int mgym_create(const mgym_config *cfg, mgym_env **out);
+int mgym_destroy(mgym_env *env);
+
+/* Launch stream (hipStream_t).  Default: a stream created by the engine. */
+int mgym_set_stream(mgym_env *env, void *hip_stream);
+void *mgym_get_stream(mgym_env *env);
+
+/* Gym::reset (cartpole.rs:238-249, mountain_car.rs:279-291, lunar_lander.rs:727-917) for the
+ * envs with mask[i] != 0 (mask == NULL: all).  obs_out may be NULL. */
+int mgym_reset(mgym_env *env, const uint8_t *mask, float *obs_out);
+
+/* mgym_reset with mask = done | truncated (either may be NULL): the "reset what just finished"
+ * call a rollout loop issues after every step. */
+int mgym_reset_done(mgym_env *env, const uint8_t *done, const uint8_t *truncated, float *obs_out);
+
+/* Gym::step (cartpole.rs:251-348, mountain_car.rs:293-330, lunar_lander.rs:919-1167).
+ * Any of obs_out / reward_out / done_out / trunc_out may be NULL (not written). */
+int mgym_step(mgym_env *env, const void *actions, float *obs_out, float *reward_out,
+              uint8_t *done_out, uint8_t *trunc_out);
+
+/* Zero-copy view of the engine-owned current observation, SoA with column stride *col_stride
+ * floats (for CartPole/MountainCar the state columns ARE the observation — `self.state.clone()`,
+ * cartpole.rs:301).  Valid until the handle is destroyed; contents follow the stream order. */
+int mgym_observation(mgym_env *env, const float **obs, uint64_t *col_stride);
+
+/* Test seam / checkpoint ≙ Testable::set_state (src/testing.rs:15-18).  blob = [state_cols][n_envs]
+ * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md. */
+int mgym_get_state(mgym_env *env, void *blob);
+int mgym_set_state(mgym_env *env, const void *blob);
+
+/* LunarLander: deterministic_mode (lunar_lander.rs:967-970) generalised — disp = [2][n_envs]
+ * raw U(-1,1) draws used instead of the per-env generator; NULL restores the generator. */
+int mgym_set_dispersion_override(mgym_env *env, const float *disp);
+
+int mgym_get_spec(int kind, mgym_spec *spec);
+
+/* Wait for the stream and return (then clear) the sticky device-side status. */
+int mgym_sync(mgym_env *env);
+
+/* Thread-local message for the last failing call on this thread. */
+const char *mgym_last_error(void);
+
+/* Plain device-memory helpers for callers without their own HIP allocator (C/C++/ctypes). */
+int mgym_malloc(int device, size_t bytes, void **out);
+int mgym_free(int device, void *ptr);
+int mgym_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int mgym_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int mgym_device_count(int *count);
+
+/* Stream timing helpers (hipEvent on the env's stream) so harnesses can time launches
+ * on the stream the kernels actually run on. */
+int mgym_timer_start(mgym_env *env);
+int mgym_timer_stop(mgym_env *env, float *elapsed_ms); /* synchronises */
+
+/* hipGraph capture of a caller-issued launch sequence on the env's stream. */
+int mgym_graph_begin(mgym_env *env);
+int mgym_graph_end(mgym_env *env, void **graph_exec_out);
+int mgym_graph_launch(mgym_env *env, void *graph_exec);
+int mgym_graph_destroy(void *graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGYM_H */

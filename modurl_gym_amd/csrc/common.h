@@ -1,0 +1,62 @@
+// common.h — engine-internal declarations shared by the kernels' host wrappers and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/mgym.h"
+
+namespace mgym {
+
+void set_last_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define MGYM_HIP(expr)                                                        \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return ::mgym::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kMaxBlocks = 8192;     // grid-stride beyond this (measured best of 2048/4096/8192/uncapped at 32 Mi envs)
+
+inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+inline int grid_for(uint64_t work_items) {
+    uint64_t b = (work_items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+// device-side sticky status bits (OR-ed into Env::d_err)
+enum : uint32_t { DEV_ERR_INVALID_ACTION = 1u, DEV_ERR_NOT_RESET = 2u };
+
+// Base of every environment family: one device, one stream, engine-owned SoA state.
+struct Env {
+    mgym_config cfg{};
+    int kind = 0;
+    int obs_dim = 0;
+    int state_cols = 0;
+    uint64_t n = 0;      // environments
+    uint64_t n_pad = 0;  // column stride (multiple of 1024 words: every column 4 KiB aligned)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t* d_err = nullptr;   // sticky device status word
+    uint32_t* h_err = nullptr;   // pinned mirror
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    virtual ~Env() {}
+    virtual int init() = 0;
+    virtual int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) = 0;
+    virtual int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) = 0;
+    virtual int observation(const float** obs, uint64_t* col_stride) = 0;
+    virtual int get_state(void* blob) = 0;
+    virtual int set_state(const void* blob) = 0;
+    virtual int set_dispersion(const float*) { set_last_error("dispersion override: LunarLander only"); return MGYM_ERR_BAD_ARG; }
+};
+
+Env* make_cartpole();
+Env* make_mountaincar(bool continuous);
+Env* make_lunarlander();
+
+}  // namespace mgym

@@ -1,0 +1,355 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (libmgym.so), against
+the CPU oracle on identical seeds/states/actions, and against the reference's golden vectors.
+
+Bar (BASELINE.json north_star): obs/reward within 1e-5 relative f32, done/truncated and
+discrete outputs bit-exact.  CartPole/MountainCar are in fact required to be BIT-IDENTICAL
+here (same operation order, no contraction, libm-identical sin/cos), which subsumes the bar.
+"""
+import numpy as np
+import pytest
+
+import modurl_gym_amd as mg
+from harness import VecAdapter, replay
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = {"cartpole": (mg.CARTPOLE, ora.CARTPOLE, 2), "mountain_car": (mg.MOUNTAINCAR, ora.MOUNTAINCAR, 3)}
+
+
+def both(name, n, seed=1, base=0, **kw):
+    k, ok, nact = PAIRS[name] if name in PAIRS else (mg.MOUNTAINCAR_CONT, ora.MOUNTAINCAR_CONT, 0)
+    okw = dict(kw)
+    okw.pop("auto_reset", None)
+    return mg.VecEnv(k, n, seed=seed, env_id_base=base, **kw), ora.OracleVec(ok, n, seed=seed, env_id_base=base, **okw), nact
+
+
+def assert_same(got, exp, what=""):
+    names = ("obs", "reward", "done", "truncated")
+    for g, e, nm in zip(got, exp, names):
+        if not np.array_equal(g, e):
+            bad = np.argwhere(g != e)
+            raise AssertionError(f"{what}{nm}: {len(bad)} mismatches, first at {bad[0]}: {g[tuple(bad[0])]} vs {e[tuple(bad[0])]}")
+
+
+# ------------------------------------------------------------------ golden vectors --------
+def test_cartpole_against_python_through_abi(golden):
+    env = mg.VecEnv(mg.CARTPOLE, 1, seed=1)
+    worst_obs, worst_rew = replay(VecAdapter(env, "cartpole"), golden("cartpole"))  # 1e-4/1e-4, testing.rs:42-45
+    assert worst_obs < 2e-7 and worst_rew == 0.0
+
+
+def test_mountain_car_against_python_through_abi(golden):
+    env = mg.VecEnv(mg.MOUNTAINCAR, 1)
+    worst_obs, worst_rew = replay(VecAdapter(env, "mountain_car"), golden("mountain_car"))
+    assert worst_obs < 2e-7 and worst_rew == 0.0
+
+
+# --------------------------------------------------- reference unit tests, same shape -----
+def test_cartpole_like_reference_unit_tests():
+    env = mg.CartPoleV1()  # cartpole.rs:365-390
+    state = env.reset()
+    assert state.shape == (4,)
+    info = env.step(np.uint32(0))
+    assert info.state.shape == (4,) and info.reward == 1.0 and not info.done
+    env = mg.CartPoleV1()  # cartpole.rs:392-403 #[should_panic]: a [1]-shaped action is rejected
+    env.reset()
+    with pytest.raises(mg.InvalidActionError):
+        env.step(np.array([1], np.uint32))
+    with pytest.raises(mg.InvalidActionError):
+        env.step(np.uint32(2))
+    env = mg.CartPoleV1()  # cartpole.rs:405-434
+    env.reset()
+    info = env.step(np.uint32(1))
+    assert info.reward == 1.0 and not info.done
+    done = False
+    for _ in range(50):
+        done = env.step(np.uint32(1)).done
+        if done:
+            break
+    assert done
+
+
+def test_mountain_car_like_reference_unit_tests():
+    env = mg.MountainCarV0()  # mountain_car.rs:347-372
+    assert env.reset().shape == (2,)
+    info = env.step(np.uint32(0))
+    assert info.state.shape == (2,) and info.reward == -1.0 and not info.done and not info.truncated
+    with pytest.raises(mg.InvalidActionError):  # mountain_car.rs:374-385
+        env.step(np.uint32(3))
+    assert env.action_space() == ("Discrete", 3)
+
+
+# ----------------------------------------------------------------- oracle parity ----------
+@pytest.mark.parametrize("name", ["cartpole", "mountain_car"])
+@pytest.mark.parametrize("n", [1, 3, 5, 64, 1023, 1025, 65536])
+def test_rollout_bit_identical_to_oracle(name, n):
+    env, ref, nact = both(name, n, seed=42 + n)
+    assert_same((env.reset(),), (ref.reset(),), "reset ")
+    rng = np.random.default_rng(n)
+    for t in range(120 if n <= 1025 else 60):
+        a = rng.integers(0, nact, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a)
+        assert_same(got, exp, f"step {t} ")
+        mask = exp[2] | exp[3]
+        if t % 3 == 0:  # reset what finished (two of three steps keep stepping finished envs: no auto-reset)
+            env.reset(mask), ref.reset(mask)
+            assert np.array_equal(env.observation(), ref.get_state()[: env.obs_dim]), f"masked reset {t}"
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_empty_population():
+    env = mg.VecEnv(mg.CARTPOLE, 0)
+    assert env.reset().shape == (4, 0)
+    obs, rew, done, trunc = env.step(np.zeros(0, np.uint32))
+    assert obs.shape == (4, 0) and rew.shape == (0,)
+
+
+def test_cartpole_config1_single_env_long_loop():
+    # BASELINE configs[0]: CartPole-v1, 1 env, step() loop with resets — plumbing through the ABI
+    env, ref, _ = both("cartpole", 1, seed=7)
+    env.reset(), ref.reset()
+    rng = np.random.default_rng(0)
+    for t in range(1500):
+        a = rng.integers(0, 2, 1).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a)
+        assert_same(got, exp, f"step {t} ")
+        if exp[2][0] or exp[3][0]:
+            assert np.array_equal(env.reset(), ref.reset())
+
+
+def test_cartpole_full_size_1mi_envs():
+    # BASELINE configs[1]: 1 048 576 envs, f32 SoA — bit-exact vs the oracle over a short rollout,
+    # plus size-independent invariants of the episode state machine.
+    n = 1 << 20
+    env, ref, _ = both("cartpole", n, seed=2024)
+    assert np.array_equal(env.reset(), ref.reset())
+    rng = np.random.default_rng(1)
+    fell = np.zeros(n, bool)
+    for t in range(30):
+        a = rng.integers(0, 2, n).astype(np.uint32)
+        got, exp = env.step(a, ), ref.step(a, nthreads=8)
+        assert_same(got, exp, f"step {t} ")
+        obs, rew, done, trunc = got
+        # invariants (steps < 500): done is exactly the threshold predicate on the returned observation,
+        # recomputed every step (cartpole.rs:291-294,310 — it is NOT sticky); reward is 1 unless the env
+        # is past its first termination (:319-346)
+        pred = (np.abs(obs[0]) > np.float32(2.4)) | (np.abs(obs[2]) > np.float32(12 * 2 * np.float32(np.pi) / 360))
+        assert np.array_equal(done.astype(bool), pred) and not trunc.any()
+        assert np.array_equal(rew == 0.0, pred & fell)
+        fell |= pred
+    assert 0.1 < fell.mean() < 1.0  # random policy: a good part of the population has fallen by step 30
+
+
+def test_mountain_car_full_size_1mi_envs():
+    n = 1 << 20  # BASELINE configs[2]
+    env, ref, _ = both("mountain_car", n, seed=11)
+    assert np.array_equal(env.reset(), ref.reset())
+    rng = np.random.default_rng(2)
+    for t in range(30):
+        a = rng.integers(0, 3, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a, nthreads=8)
+        assert_same(got, exp, f"step {t} ")
+    obs = got[0]
+    assert (obs[0] >= np.float32(-1.2)).all() and (obs[0] <= np.float32(0.6)).all() and (np.abs(obs[1]) <= np.float32(0.07)).all()
+    assert (got[1] == -1.0).all() and not got[3].any()
+
+
+def test_mountain_car_continuous_vs_oracle():
+    n = 1 << 20  # BASELINE configs[2], second half — NOT in the reference: parity unpinned
+    env, ref, _ = both("mountain_car_cont", n, seed=5)
+    assert np.array_equal(env.reset(), ref.reset())
+    rng = np.random.default_rng(3)
+    for t in range(20):
+        a = rng.uniform(-1.5, 1.5, n).astype(np.float32)
+        got, exp = env.step(a), ref.step(a, nthreads=8)
+        assert_same(got, exp, f"step {t} ")
+    small = mg.VecEnv(mg.MOUNTAINCAR_CONT, 4)
+    with pytest.raises(mg.InvalidActionError):
+        small.step(np.array([0.0, np.nan, 0.0, 0.0], np.float32))
+
+
+# ----------------------------------------------------- forced branches (rare paths) --------
+def u32col(x):
+    return np.array(x, np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("sb", [False, True])
+@pytest.mark.parametrize("euler", [True, False])
+def test_cartpole_all_branches_vs_oracle(sb, euler):
+    n = 4096
+    env, ref, _ = both("cartpole", n, seed=3, sutton_barto_reward=sb, is_euler=euler)
+    env.reset(), ref.reset()
+    rng = np.random.default_rng(9)
+    s = ref.get_state()
+    s[0] = rng.uniform(-2.6, 2.6, n)          # x around the +-2.4 threshold
+    s[1] = rng.uniform(-3, 3, n)
+    s[2] = rng.uniform(-0.25, 0.25, n)        # theta around +-0.2094
+    s[3] = rng.uniform(-3, 3, n)
+    s[4] = u32col(rng.integers(490, 503, n))  # steps around the 500-step truncation
+    s[5] = u32col(rng.integers(-1, 3, n).astype(np.int32).view(np.uint32))  # sbt None / Some(k)
+    ref.set_state(s), env.set_state(s)
+    seen_trunc = seen_post = 0
+    for t in range(12):
+        a = rng.integers(0, 2, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a)
+        assert_same(got, exp, f"step {t} ")
+        seen_trunc += int(exp[3].sum())
+        seen_post += int(((exp[2] == 1) & (exp[1] == (-1.0 if sb else 0.0))).sum())
+    assert seen_trunc > 0 and seen_post > 0  # truncation-beats-termination and post-terminal paths were hit
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_cartpole_large_angles_use_table_reduction():
+    # stepping long after termination spins theta up: exercises reduce_fast beyond pi/4 and the
+    # |x| >= 120 table reduction of mgym_math.h on the device
+    n = 8192
+    env, ref, _ = both("cartpole", n, seed=4)
+    rng = np.random.default_rng(10)
+    s = ref.get_state()
+    mag = np.concatenate([rng.uniform(0, 16, n // 2), 10.0 ** rng.uniform(np.log10(120), 6, n // 2)])
+    s[2] = (mag * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    s[3] = rng.uniform(-1, 1, n)
+    ref.set_state(s), env.set_state(s)
+    a = rng.integers(0, 2, n).astype(np.uint32)
+    assert_same(env.step(a), ref.step(a), "large-angle ")
+
+
+def test_mountain_car_clamps_wall_goal_vs_oracle():
+    n = 4096
+    for gv in (0.0, 0.03):
+        env, ref, _ = both("mountain_car", n, seed=6, goal_velocity=gv)
+        rng = np.random.default_rng(12)
+        s = ref.get_state()
+        s[0] = rng.choice([-1.2, -1.19, 0.49, 0.5, 0.59, 0.6, -0.5], n).astype(np.float32)
+        s[1] = rng.uniform(-0.07, 0.07, n)
+        ref.set_state(s), env.set_state(s)
+        hit_goal = hit_wall = 0
+        for t in range(8):
+            a = rng.integers(0, 3, n).astype(np.uint32)
+            got, exp = env.step(a), ref.step(a)
+            assert_same(got, exp, f"gv={gv} step {t} ")
+            hit_goal += int(exp[2].sum())
+            hit_wall += int(((exp[0][0] == np.float32(-1.2)) & (exp[0][1] == 0.0)).sum())
+        assert hit_goal > 0 and hit_wall > 0
+
+
+# ----------------------------------------------------------- error behaviour, API edges -----
+def test_invalid_action_is_reported_and_sticky_until_sync():
+    env = mg.VecEnv(mg.CARTPOLE, 1000)
+    env.reset()
+    a = np.zeros(1000, np.uint32)
+    a[777] = 2
+    with pytest.raises(mg.InvalidActionError):
+        env.step(a)
+    env.step(np.zeros(1000, np.uint32))  # cleared by the failing sync; engine stays usable
+
+
+def test_unaligned_caller_buffers_take_the_scalar_kernel():
+    n = 1000
+    env, ref, _ = both("cartpole", n, seed=8)
+    env.reset(), ref.reset()
+    a = np.random.default_rng(0).integers(0, 2, n).astype(np.uint32)
+    big = mg.DeviceArray(n + 8, np.uint32)
+    rew = mg.DeviceArray(n + 8, np.float32)
+    done = mg.DeviceArray(n + 8, np.uint8)
+    trunc = mg.DeviceArray(n + 8, np.uint8)
+    obs = mg.DeviceArray(4 * n + 8, np.float32)
+    big.copy_from(np.concatenate([[0], a, np.zeros(7)]).astype(np.uint32))
+    env.step_device(big.ptr + 4, obs.ptr + 4, rew.ptr + 4, done.ptr + 1, trunc.ptr + 3)  # all misaligned
+    env.sync()
+    exp = ref.step(a)
+    assert np.array_equal(obs.numpy()[1:1 + 4 * n].reshape(4, n), exp[0])
+    assert np.array_equal(rew.numpy()[1:1 + n], exp[1])
+    assert np.array_equal(done.numpy()[1:1 + n], exp[2]) and np.array_equal(trunc.numpy()[3:3 + n], exp[3])
+
+
+def test_null_outputs_and_zero_copy_observation():
+    n = 4096
+    env, ref, _ = both("cartpole", n, seed=13)
+    env.reset(), ref.reset()
+    a = np.random.default_rng(1).integers(0, 2, n).astype(np.uint32)
+    act = mg.DeviceArray.from_numpy(a)
+    env.step_device(act)  # every output NULL: the 50 B/env-step configuration minus reward/flags
+    env.sync()
+    exp = ref.step(a)
+    assert np.array_equal(env.observation(), exp[0])
+    ptr, stride = env.observation_device()
+    assert ptr % 4096 == 0 and stride % 1024 == 0 and stride >= n
+
+
+def test_auto_reset_flag_equals_step_then_masked_reset():
+    n = 20000
+    for name in ("cartpole", "mountain_car"):
+        env, ref, nact = both(name, n, seed=21, auto_reset=True)
+        env.reset(), ref.reset()
+        if name == "mountain_car":  # start near the goal so some envs finish
+            s = ref.get_state(); s[0] = 0.48; s[1] = 0.03; ref.set_state(s); env.set_state(s)
+        rng = np.random.default_rng(4)
+        for t in range(60):
+            a = rng.integers(0, nact, n).astype(np.uint32)
+            got, exp = env.step(a), ref.step(a)
+            assert_same(got[1:], exp[1:], f"{name} step {t} ")  # reward/done/trunc of the step itself
+            ref.reset(mask=exp[2] | exp[3])
+            st = ref.get_state()
+            assert np.array_equal(env.observation(), st[: env.obs_dim]), f"{name} step {t}: post-reset obs"
+        assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_reset_done_device_matches_masked_reset():
+    n = 5000
+    env, ref, _ = both("cartpole", n, seed=30)
+    env.reset(), ref.reset()
+    rng = np.random.default_rng(6)
+    act, rew = mg.DeviceArray(n, np.uint32), mg.DeviceArray(n, np.float32)
+    done, trunc = mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)
+    for t in range(40):
+        a = rng.integers(0, 2, n).astype(np.uint32)
+        act.copy_from(a)
+        env.step_device(act, None, rew, done, trunc)
+        env.reset_done_device(done, trunc)
+        env.sync()
+        exp = ref.step(a)
+        ref.reset(mask=exp[2] | exp[3])
+        assert np.array_equal(done.numpy(), exp[2])
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_sharding_is_invisible_global_env_ids():
+    # results are bit-identical however the population is sharded
+    n = 6000
+    whole = mg.VecEnv(mg.CARTPOLE, n, seed=77)
+    parts = [mg.VecEnv(mg.CARTPOLE, c, seed=77, env_id_base=s) for s, c in ((0, 1500), (1500, 3000), (4500, 1500))]
+    a = np.random.default_rng(8).integers(0, 2, (25, n)).astype(np.uint32)
+    assert np.array_equal(whole.reset(), np.concatenate([p.reset() for p in parts], axis=1))
+    for t in range(25):
+        w = whole.step(a[t])
+        ps = [p.step(a[t][s:s + c]) for p, (s, c) in zip(parts, ((0, 1500), (1500, 3000), (4500, 1500)))]
+        assert np.array_equal(w[0], np.concatenate([x[0] for x in ps], axis=1))
+        m = w[2] | w[3]
+        whole.reset(m)
+        for p, (s, c) in zip(parts, ((0, 1500), (1500, 3000), (4500, 1500))):
+            p.reset(m[s:s + c])
+    assert np.array_equal(whole.get_state()[:4], np.concatenate([p.get_state()[:4] for p in parts], axis=1))
+
+
+def test_graph_replay_equals_eager():
+    n = 8192
+    env, ref, _ = both("cartpole", n, seed=31)
+    env.reset(), ref.reset()
+    a = np.random.default_rng(11).integers(0, 2, n).astype(np.uint32)
+    act, rew = mg.DeviceArray.from_numpy(a), mg.DeviceArray(n, np.float32)
+    done, trunc = mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)
+
+    def body():
+        env.step_device(act, None, rew, done, trunc)
+        env.reset_done_device(done, trunc)
+
+    g = env.graph_capture(body)
+    for t in range(10):
+        env.graph_launch(g)
+        exp = ref.step(a)
+        ref.reset(mask=exp[2] | exp[3])
+    env.sync()
+    env.graph_destroy(g)
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
