@@ -146,6 +146,8 @@ int ora_vec_step(ora_vec *v, const void *actions, float *obs_soa, float *reward,
 int ora_vec_state_cols(const ora_vec *v);
 void ora_vec_get_state(const ora_vec *v, float *soa);
 void ora_vec_set_state(ora_vec *v, const float *soa);
+/* lunar lander only: Testable::reset_deterministic on every env (lunar_lander.rs:1249-1442) */
+int ora_vec_reset_deterministic(ora_vec *v, float *obs_soa);
 /* lunar lander only: per-env dispersion override ([2][n] raw draws), NULL = generator */
 void ora_vec_set_dispersion(ora_vec *v, const float *disp_soa);
 

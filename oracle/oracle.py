@@ -92,6 +92,7 @@ def lib():
         L.ora_vec_get_state.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_vec_set_state.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_vec_set_dispersion.argtypes = [C.c_void_p, C.c_void_p]
+        L.ora_vec_reset_deterministic.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -136,6 +137,13 @@ class OracleVec:
             raise RuntimeError(f"oracle reset status {st}")
         return obs
 
+    def reset_deterministic(self):
+        obs = np.zeros((self.obs_dim, self.n), np.float32)
+        st = lib().ora_vec_reset_deterministic(self._h, _ptr(obs))
+        if st != OK:
+            raise RuntimeError(f"oracle reset_deterministic status {st}")
+        return obs
+
     def step(self, actions, nthreads=1, out=None):
         a = np.ascontiguousarray(actions, np.float32 if self.kind == MOUNTAINCAR_CONT else np.uint32)
         assert a.shape == (self.n,)
@@ -146,6 +154,8 @@ class OracleVec:
         st = lib().ora_vec_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc), nthreads)
         if st == INVALID_ACTION:
             raise ValueError("invalid action")
+        if st == NOT_RESET:
+            raise RuntimeError("You forgot to call reset()")
         if st != OK:
             raise RuntimeError(f"oracle step status {st}")
         return obs, rew, done, trunc

@@ -282,3 +282,16 @@ void ora_vec_set_state(ora_vec *v, const float *soa) {
 }
 
 void ora_vec_set_dispersion(ora_vec *v, const float *disp_soa) { v->disp_override = disp_soa; }
+
+int ora_vec_reset_deterministic(ora_vec *v, float *obs_soa) {
+    if (v->cfg.kind != 3) return ORA_BAD_CONFIG;
+    size_t n = (size_t)v->cfg.n_envs;
+    for (size_t i = 0; i < n; ++i) {
+        float obs[8];
+        int st = ora_lunarlander_reset_deterministic(v->ll[i], obs);
+        if (st != ORA_OK) return st;
+        v->ll_step[i] = 1;
+        if (obs_soa) for (int k = 0; k < 8; ++k) obs_soa[(size_t)k * n + i] = obs[k];
+    }
+    return ORA_OK;
+}

@@ -59,12 +59,23 @@ class VecAdapter:
             s = self.v.get_state()
             s[0:2, :] = 0.0
             self.v.set_state(s)
+        elif self.kind == "lunar_lander":
+            self.v.reset_deterministic()  # lunar_lander.rs:1249-1442
         else:
             raise NotImplementedError
 
     def set_state(self, obs, info):
         s = self.v.get_state()
-        s[0:len(obs), 0] = np.asarray(obs, np.float32)  # cartpole.rs:444-446 / mountain_car.rs:410-412
+        if self.kind == "lunar_lander":
+            # lunar_lander.rs:1444-1554: raw physics values from `info`, leg contact flags; the blob's
+            # words 0..19 carry exactly that (set_state ignores the rest)
+            keys = [f"raw_{b}_{k}" for b in ("lander", "leg0", "leg1")
+                    for k in ("pos_x", "pos_y", "angle", "vel_x", "vel_y", "angular_vel")]
+            s[0:18, 0] = np.asarray([info[k] for k in keys], np.float32)
+            s[18, 0] = 1.0 if info.get("leg0_contact", 0.0) > 0.5 else 0.0
+            s[19, 0] = 1.0 if info.get("leg1_contact", 0.0) > 0.5 else 0.0
+        else:
+            s[0:len(obs), 0] = np.asarray(obs, np.float32)  # cartpole.rs:444-446 / mountain_car.rs:410-412
         self.v.set_state(s)
 
     def step(self, action):
