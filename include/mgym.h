@@ -49,7 +49,8 @@ typedef enum mgym_status {
     MGYM_ERR_BAD_CONFIG = 3,     /* assert!(-12.0 < gravity && gravity < 0.0): lunar_lander.rs:292-296 */
     MGYM_ERR_HIP = 4,            /* HIP runtime failure (reference: candle_core::Error from tensor ops) */
     MGYM_ERR_BAD_ARG = 5,        /* null/misaligned pointer, wrong kind */
-    MGYM_ERR_NO_DEVICE = 6       /* no gfx950 device / HIP runtime unusable: the engine has no CPU fallback */
+    MGYM_ERR_NO_DEVICE = 6,      /* no gfx950 device / HIP runtime unusable: the engine has no CPU fallback */
+    MGYM_ERR_CAPACITY = 7        /* LunarLander: more simultaneous ground contacts than the per-env cache holds (12) */
 } mgym_status;
 
 typedef enum mgym_kind {
@@ -137,6 +138,11 @@ int mgym_observation(mgym_env *env, const float **obs, uint64_t *col_stride);
  * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md. */
 int mgym_get_state(mgym_env *env, void *blob);
 int mgym_set_state(mgym_env *env, const void *blob);
+
+/* Test seam ≙ Testable::reset_deterministic (cartpole.rs:437-442: reset() then state = 0;
+ * mountain_car.rs:403-408: state = 0; lunar_lander.rs:1249-1442: flat terrain, lander at
+ * (W/2, 0.8 H) falling at 1 m/s, deterministic_mode = true) applied to every env. obs_out may be NULL. */
+int mgym_reset_deterministic(mgym_env *env, float *obs_out);
 
 /* LunarLander: deterministic_mode (lunar_lander.rs:967-970) generalised — disp = [2][n_envs]
  * raw U(-1,1) draws used instead of the per-env generator; NULL restores the generator. */

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgym.so")
 
-OK, ERR_INVALID_ACTION, ERR_NOT_RESET, ERR_BAD_CONFIG, ERR_HIP, ERR_BAD_ARG, ERR_NO_DEVICE = range(7)
+OK, ERR_INVALID_ACTION, ERR_NOT_RESET, ERR_BAD_CONFIG, ERR_HIP, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_CAPACITY = range(8)
 CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, LUNARLANDER = range(4)
 FLAG_AUTO_RESET = 1
 
@@ -42,6 +42,7 @@ PROTOTYPES = {
     "mgym_get_stream": (_vp, [_vp]),
     "mgym_reset": (C.c_int, [_vp, _vp, _vp]),
     "mgym_reset_done": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mgym_reset_deterministic": (C.c_int, [_vp, _vp]),
     "mgym_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgym_observation": (C.c_int, [_vp, C.POINTER(_vp), _u64p]),
     "mgym_get_state": (C.c_int, [_vp, _vp]),

@@ -87,7 +87,7 @@ int mgym_get_spec(int kind, mgym_spec* s) {
         else { s->n_actions = 0; s->action_is_float = 1; s->action_low = -1.0f; s->action_high = 1.0f; }
         break;
     case MGYM_LUNARLANDER: {  // lunar_lander.rs:1169-1200
-        s->obs_dim = 8; s->n_actions = 4; s->state_cols = 0;
+        s->obs_dim = 8; s->n_actions = 4; s->state_cols = 27;
         const float twopi = 2.0f * 3.14159265358979323846f;
         const float hi[8] = {2.5f, 2.5f, 10.0f, 10.0f, twopi, 10.0f, 1.0f, 1.0f};
         for (int k = 0; k < 8; ++k) { s->obs_high[k] = hi[k]; s->obs_low[k] = k < 6 ? -hi[k] : 0.0f; }
@@ -208,6 +208,11 @@ int mgym_reset_done(mgym_env* env, const uint8_t* done, const uint8_t* truncated
     return e->reset(done, truncated, false, obs_out);
 }
 
+int mgym_reset_deterministic(mgym_env* env, float* obs_out) {
+    ENV_OR_FAIL(env);
+    return e->reset_deterministic(obs_out);
+}
+
 int mgym_step(mgym_env* env, const void* actions, float* obs_out, float* reward_out, uint8_t* done_out,
               uint8_t* trunc_out) {
     ENV_OR_FAIL(env);
@@ -247,6 +252,10 @@ int mgym_sync(mgym_env* env) {
     if (bits & DEV_ERR_INVALID_ACTION) {
         set_last_error("invalid action: assertion `action_space.contains(&action)` failed for at least one environment");
         return MGYM_ERR_INVALID_ACTION;
+    }
+    if (bits & DEV_ERR_CONTACT_OVERFLOW) {
+        set_last_error("LunarLander: contact cache overflow (more than 12 simultaneous ground contacts in one environment)");
+        return MGYM_ERR_CAPACITY;
     }
     if (bits & DEV_ERR_NOT_RESET) {
         set_last_error("You forgot to call reset()");

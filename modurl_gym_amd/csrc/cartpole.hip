@@ -410,6 +410,14 @@ struct CartPoleEnv final : Env {
         return MGYM_OK;
     }
 
+    int reset_deterministic(float* obs_out) override {  // cartpole.rs:437-442: self.reset()? then state = zeros
+        int st = reset(nullptr, nullptr, true, nullptr);
+        if (st != MGYM_OK || n == 0) return st;
+        MGYM_HIP(hipMemsetAsync(dev.x, 0, 4 * n_pad * sizeof(float), stream));
+        if (obs_out) MGYM_HIP(hipMemsetAsync(obs_out, 0, 4 * n * sizeof(float), stream));
+        return MGYM_OK;
+    }
+
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
         const uint32_t* act = static_cast<const uint32_t*>(actions);

@@ -29,7 +29,7 @@ inline int grid_for(uint64_t work_items) {
 }
 
 // device-side sticky status bits (OR-ed into Env::d_err)
-enum : uint32_t { DEV_ERR_INVALID_ACTION = 1u, DEV_ERR_NOT_RESET = 2u };
+enum : uint32_t { DEV_ERR_INVALID_ACTION = 1u, DEV_ERR_NOT_RESET = 2u, DEV_ERR_CONTACT_OVERFLOW = 4u };
 
 // Base of every environment family: one device, one stream, engine-owned SoA state.
 struct Env {
@@ -52,6 +52,9 @@ struct Env {
     virtual int observation(const float** obs, uint64_t* col_stride) = 0;
     virtual int get_state(void* blob) = 0;
     virtual int set_state(const void* blob) = 0;
+    // Testable::reset_deterministic of the reference's test modules (cartpole.rs:437-442, mountain_car.rs:403-408,
+    // lunar_lander.rs:1249-1442)
+    virtual int reset_deterministic(float* obs_out) = 0;
     virtual int set_dispersion(const float*) { set_last_error("dispersion override: LunarLander only"); return MGYM_ERR_BAD_ARG; }
 };
 

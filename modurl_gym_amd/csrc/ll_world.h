@@ -1,0 +1,785 @@
+// ll_world.h — per-lane "world" of one LunarLander environment: contact manager, island solver,
+// revolute joints, continuous (TOI) solver and b2World::Step, restated for gfx950 (see ll_b2.h).
+// Follows Box2D v2.4.1's b2ContactManager / b2Island / b2RevoluteJoint / b2World; the call site being
+// replaced is `world.borrow_mut().step(1.0 / FPS, 6 * 30, 2 * 30)` (reference lunar_lander.rs:1066).
+#pragma once
+#include "ll_b2.h"
+
+namespace mgym {
+namespace ll {
+
+struct Joint {  // b2RevoluteJoint, bodyA = lander (0), bodyB = leg (1 + j)
+    V2 impulse; float motorImpulse, lowerImpulse, upperImpulse;
+    // solver temporaries
+    V2 rA, rB;
+    float K11, K12, K21, K22, angle, axialMass;
+};
+
+struct World {
+    Body b[3];
+    Contact ct[kSlots];
+    Joint jt[2];
+    float smooth[kEdges];   // terrain heights smooth_y[0..10] (lunar_lander.rs:772-774)
+    AABB fat[3];            // broad-phase AABBs of the three polygon proxies
+    uint32_t next_seq;
+    uint32_t pending;       // bits 0..2: proxy of body i waits in the move buffer (test seam only)
+    bool newContacts, stepped_once;
+    bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
+    bool overflow;            // contact cache exhausted (reported through the sticky status)
+    bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
+};
+
+constexpr float kW = 600.0f / 30.0f;  // VIEWPORT_W / SCALE
+
+LLD void edge_verts(const World& w, int e, V2& v1, V2& v2) {
+    if (e == 0) { v1 = mk(0.0f, 0.0f); v2 = mk(kW, 0.0f); return; }  // lunar_lander.rs:785
+    const float cw = kW / 10.0f;                                     // :758-760
+    v1 = mk(cw * (float)(e - 1), w.smooth[e - 1]);                   // :796-800
+    v2 = mk(cw * (float)e, w.smooth[e]);
+}
+LLD AABB edge_fat(const World& w, int e) {  // b2EdgeShape::ComputeAABB + b2DynamicTree::CreateProxy
+    V2 v1, v2;
+    edge_verts(w, e, v1, v2);
+    V2 lower = mk(fmin2(v1.x, v2.x), fmin2(v1.y, v2.y)), upper = mk(fmax2(v1.x, v2.x), fmax2(v1.y, v2.y));
+    AABB a;
+    a.lo = mk((lower.x - b2_polygonRadius) - b2_aabbExtension, (lower.y - b2_polygonRadius) - b2_aabbExtension);
+    a.hi = mk((upper.x + b2_polygonRadius) + b2_aabbExtension, (upper.y + b2_polygonRadius) + b2_aabbExtension);
+    return a;
+}
+LLD AABB poly_aabb(const PolyTab& tab, int pi, Xf xf) {  // b2PolygonShape::ComputeAABB
+    V2 lower = xmul(xf, tab.v[pi][0]), upper = lower;
+    for (int i = 1; i < tab.count[pi]; ++i) {
+        V2 v = xmul(xf, tab.v[pi][i]);
+        lower = mk(fmin2(lower.x, v.x), fmin2(lower.y, v.y));
+        upper = mk(fmax2(upper.x, v.x), fmax2(upper.y, v.y));
+    }
+    AABB a;
+    a.lo = mk(lower.x - b2_polygonRadius, lower.y - b2_polygonRadius);
+    a.hi = mk(upper.x + b2_polygonRadius, upper.y + b2_polygonRadius);
+    return a;
+}
+LLD bool aabb_contains(AABB a, AABB b) { return a.lo.x <= b.lo.x && a.lo.y <= b.lo.y && b.hi.x <= a.hi.x && b.hi.y <= a.hi.y; }
+LLD bool aabb_overlap(AABB a, AABB b) {
+    V2 d1 = b.lo - a.hi, d2 = a.lo - b.hi;
+    if (d1.x > 0.0f || d1.y > 0.0f) return false;
+    if (d2.x > 0.0f || d2.y > 0.0f) return false;
+    return true;
+}
+LLD int poly_of(int body) { return body == 0 ? 0 : 1; }
+
+// b2DynamicTree::MoveProxy; returns true when the proxy was re-inserted (=> buffered move)
+LLD bool move_proxy(World& w, int body, AABB aabb, V2 displacement) {
+    AABB fatAABB;
+    fatAABB.lo = mk(aabb.lo.x - b2_aabbExtension, aabb.lo.y - b2_aabbExtension);
+    fatAABB.hi = mk(aabb.hi.x + b2_aabbExtension, aabb.hi.y + b2_aabbExtension);
+    V2 d = b2_aabbMultiplier * displacement;
+    if (d.x < 0.0f) fatAABB.lo.x += d.x; else fatAABB.hi.x += d.x;
+    if (d.y < 0.0f) fatAABB.lo.y += d.y; else fatAABB.hi.y += d.y;
+    AABB treeAABB = w.fat[body];
+    if (aabb_contains(treeAABB, aabb)) {
+        AABB huge;
+        huge.lo = mk(fatAABB.lo.x - 4.0f * b2_aabbExtension, fatAABB.lo.y - 4.0f * b2_aabbExtension);
+        huge.hi = mk(fatAABB.hi.x + 4.0f * b2_aabbExtension, fatAABB.hi.y + 4.0f * b2_aabbExtension);
+        if (aabb_contains(huge, treeAABB)) return false;
+    }
+    w.fat[body] = fatAABB;
+    return true;
+}
+LLD bool fixture_sync(World& w, const PolyTab& tab, int body, Xf xf1, Xf xf2) {  // b2Fixture::Synchronize
+    AABB a1 = poly_aabb(tab, poly_of(body), xf1), a2 = poly_aabb(tab, poly_of(body), xf2);
+    AABB aabb;
+    aabb.lo = mk(fmin2(a1.lo.x, a2.lo.x), fmin2(a1.lo.y, a2.lo.y));
+    aabb.hi = mk(fmax2(a1.hi.x, a2.hi.x), fmax2(a1.hi.y, a2.hi.y));
+    V2 c1 = 0.5f * (a1.lo + a1.hi), c2 = 0.5f * (a2.lo + a2.hi);
+    return move_proxy(w, body, aabb, c2 - c1);
+}
+LLD bool body_sync_fixtures(World& w, const PolyTab& tab, int body) {  // b2Body::SynchronizeFixtures
+    Body& b = w.b[body];
+    if (b.awake) {
+        Xf xf1;
+        xf1.q = rot_set(b.sw.a0);
+        xf1.p = b.sw.c0 - rmul(xf1.q, b.sw.localCenter);
+        return fixture_sync(w, tab, body, xf1, b.xf);
+    }
+    return fixture_sync(w, tab, body, b.xf, b.xf);
+}
+
+LLD int find_slot(const World& w, int body, int edge) {
+    for (int s = 0; s < kSlots; ++s)
+        if (w.ct[s].exists && w.ct[s].body == body && w.ct[s].edge == edge) return s;
+    return -1;
+}
+// b2ContactManager::AddPair (ground edge, dynamic polygon)
+LLD void add_pair(World& w, int edge, int body) {
+    if (find_slot(w, body, edge) >= 0) return;
+    int s = -1;
+    for (int k = 0; k < kSlots; ++k)
+        if (!w.ct[k].exists) { s = k; break; }
+    if (s < 0) { w.overflow = true; return; }
+    Contact& c = w.ct[s];
+    c.exists = true; c.touching = false; c.enabled = true; c.islandFlag = false; c.toiFlag = false;
+    c.seq = w.next_seq++;
+    c.body = body; c.edge = edge;
+    c.m.pointCount = 0; c.m.type = 0;
+    c.toiCount = 0; c.toi = 1.0f;
+}
+// b2BroadPhase::UpdatePairs for the buffered moves `order[0..n)` (dynamic proxies; partners = ground edges
+// by ascending proxy id — the brute-force stand-in for the dynamic-tree query, as in the CPU oracle)
+LLD void find_new_contacts(World& w, const int* order, int n) {
+    for (int i = 0; i < n; ++i) {
+        int body = order[i];
+        // no ground proxy can overlap a box that lies entirely above the highest terrain vertex
+        for (int e = 0; e < kEdges; ++e)
+            if (aabb_overlap(w.fat[body], edge_fat(w, e))) add_pair(w, e, body);
+    }
+}
+
+// ContactDetector::begin_contact / end_contact (lunar_lander.rs:154-205); body ids: lander 1, legs 2/3, ground 0
+LLD void on_begin(World& w, int body) {
+    if (body == 0) w.game_over = true;
+    else w.legs[body - 1] = true;
+}
+LLD void on_end(World& w, int body) {
+    if (body != 0) w.legs[body - 1] = false;
+}
+
+LLD void contact_update(World& w, const PolyTab& tab, Contact& c) {  // b2Contact::Update
+    Manifold oldManifold = c.m;
+    c.enabled = true;
+    bool wasTouching = c.touching;
+    V2 v1, v2;
+    edge_verts(w, c.edge, v1, v2);
+    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), w.b[c.body].xf);
+    bool touching = c.m.pointCount > 0;
+    for (int i = 0; i < c.m.pointCount; ++i) {
+        MPoint& mp2 = c.m.points[i];
+        mp2.normalImpulse = 0.0f;
+        mp2.tangentImpulse = 0.0f;
+        for (int j = 0; j < oldManifold.pointCount; ++j) {
+            const MPoint& mp1 = oldManifold.points[j];
+            if (cf_equal(mp1.id, mp2.id)) {
+                mp2.normalImpulse = mp1.normalImpulse;
+                mp2.tangentImpulse = mp1.tangentImpulse;
+                break;
+            }
+        }
+    }
+    if (touching != wasTouching) body_set_awake(w.b[c.body], true);
+    c.touching = touching;
+    if (!wasTouching && touching) on_begin(w, c.body);
+    if (wasTouching && !touching) on_end(w, c.body);
+}
+
+// contact list order: newest first
+LLD int contact_order(const World& w, int* order) {
+    int n = 0;
+    for (int s = 0; s < kSlots; ++s)
+        if (w.ct[s].exists) order[n++] = s;
+    for (int i = 1; i < n; ++i) {
+        int k = order[i], j = i - 1;
+        while (j >= 0 && w.ct[order[j]].seq < w.ct[k].seq) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = k;
+    }
+    return n;
+}
+
+LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
+    int order[kSlots];
+    int n = contact_order(w, order);
+    for (int k = 0; k < n; ++k) {
+        Contact& c = w.ct[order[k]];
+        if (!w.b[c.body].awake) continue;
+        if (!aabb_overlap(edge_fat(w, c.edge), w.fat[c.body])) {  // b2ContactManager::Destroy
+            if (c.touching) on_end(w, c.body);
+            if (c.m.pointCount > 0) body_set_awake(w.b[c.body], true);
+            c.exists = false;
+            continue;
+        }
+        contact_update(w, tab, c);
+    }
+}
+
+// ---- contact solver over a list of slots --------------------------------------------------------------
+struct CSolver {
+    VConstraint vc[kSlots];
+    PConstraint pc[kSlots];
+    int count;
+};
+
+LLD void cs_init(CSolver& s, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
+    s.count = count;
+    for (int i = 0; i < count; ++i) {
+        Contact& contact = w.ct[slots[i]];
+        const Manifold& manifold = contact.m;
+        const int t = poly_of(contact.body);
+        VConstraint& vc = s.vc[i];
+        vc.friction = k.friction[t];
+        vc.indexB = contact.body;
+        vc.invMassB = k.invMass[t]; vc.invIB = k.invI[t];
+        vc.slot = slots[i]; vc.pointCount = manifold.pointCount;
+        vc.k11 = vc.k12 = vc.k21 = vc.k22 = 0.0f; vc.nm11 = vc.nm12 = vc.nm21 = vc.nm22 = 0.0f;
+        PConstraint& pc = s.pc[i];
+        pc.indexB = contact.body; pc.invMassB = k.invMass[t]; pc.invIB = k.invI[t];
+        pc.localCenterB = k.localCenter[t];
+        pc.localNormal = manifold.localNormal; pc.localPoint = manifold.localPoint;
+        pc.pointCount = manifold.pointCount; pc.type = manifold.type;
+        for (int j = 0; j < manifold.pointCount; ++j) {
+            const MPoint& cp = manifold.points[j];
+            VCPoint& vcp = vc.points[j];
+            if (warmStarting) {
+                vcp.normalImpulse = dtRatio * cp.normalImpulse;
+                vcp.tangentImpulse = dtRatio * cp.tangentImpulse;
+            } else {
+                vcp.normalImpulse = 0.0f; vcp.tangentImpulse = 0.0f;
+            }
+            vcp.rB = mk(0.0f, 0.0f);
+            vcp.normalMass = 0.0f; vcp.tangentMass = 0.0f; vcp.velocityBias = 0.0f;
+            pc.localPoints[j] = cp.localPoint;
+        }
+    }
+}
+
+// b2ContactSolver::InitializeVelocityConstraints.  restitution = 0: velocityBias = -0 * vRel (a signed
+// zero when vRel < -threshold), which only ever enters `vn - velocityBias` and is therefore left at 0.
+LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel* vel) {
+    for (int i = 0; i < s.count; ++i) {
+        VConstraint& vc = s.vc[i];
+        const PConstraint& pc = s.pc[i];
+        const Manifold& manifold = w.ct[vc.slot].m;
+        const float mB = vc.invMassB, iB = vc.invIB;
+        V2 cB = pos[vc.indexB].c; float aB = pos[vc.indexB].a;
+        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        Xf xfB;
+        xfB.q = rot_set(aB);
+        xfB.p = cB - rmul(xfB.q, pc.localCenterB);
+        V2 wm_normal = mk(0.0f, 0.0f), wm_points[2];
+        world_manifold(manifold, xfB, wm_normal, wm_points);
+        vc.normal = wm_normal;
+        for (int j = 0; j < vc.pointCount; ++j) {
+            VCPoint& vcp = vc.points[j];
+            vcp.rB = wm_points[j] - cB;
+            float rnB = cross(vcp.rB, vc.normal);
+            float kNormal = mB + iB * rnB * rnB;
+            vcp.normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+            V2 tangent = cross_vs(vc.normal, 1.0f);
+            float rtB = cross(vcp.rB, tangent);
+            float kTangent = mB + iB * rtB * rtB;
+            vcp.tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+            float vRel = dot(vc.normal, vB + cross_sv(wB, vcp.rB));
+            vcp.velocityBias = 0.0f;
+            if (vRel < -1.0f) vcp.velocityBias = -0.0f * vRel;
+        }
+        if (vc.pointCount == 2) {
+            float rn1B = cross(vc.points[0].rB, vc.normal);
+            float rn2B = cross(vc.points[1].rB, vc.normal);
+            float k11 = mB + iB * rn1B * rn1B;
+            float k22 = mB + iB * rn2B * rn2B;
+            float k12 = mB + iB * rn1B * rn2B;
+            const float k_maxConditionNumber = 1000.0f;
+            if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+                vc.k11 = k11; vc.k21 = k12; vc.k12 = k12; vc.k22 = k22;
+                float a = k11, b = k12, c = k12, d = k22;
+                float det = a * d - b * c;
+                if (det != 0.0f) det = 1.0f / det;
+                vc.nm11 = det * d; vc.nm12 = -det * b; vc.nm21 = -det * c; vc.nm22 = det * a;
+            } else {
+                vc.pointCount = 1;
+            }
+        }
+    }
+}
+
+LLD void cs_warm_start(const CSolver& s, Vel* vel) {  // b2ContactSolver::WarmStart
+    for (int i = 0; i < s.count; ++i) {
+        const VConstraint& vc = s.vc[i];
+        const float mB = vc.invMassB, iB = vc.invIB;
+        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
+        for (int j = 0; j < vc.pointCount; ++j) {
+            const VCPoint& vcp = vc.points[j];
+            V2 P = vcp.normalImpulse * normal + vcp.tangentImpulse * tangent;
+            wB += iB * cross(vcp.rB, P);
+            vB = vB + mB * P;
+        }
+        vel[vc.indexB].v = vB; vel[vc.indexB].w = wB;
+    }
+}
+
+LLD void cs_apply2(const VConstraint& vc, V2 x, V2 a, V2 normal, V2& vB, float& wB, VCPoint& cp1, VCPoint& cp2) {
+    V2 d = x - a;
+    V2 P1 = d.x * normal, P2 = d.y * normal;
+    vB = vB + vc.invMassB * (P1 + P2);
+    wB += vc.invIB * (cross(cp1.rB, P1) + cross(cp2.rB, P2));
+    cp1.normalImpulse = x.x; cp2.normalImpulse = x.y;
+}
+
+LLD void cs_solve_velocity(CSolver& s, Vel* vel) {  // b2ContactSolver::SolveVelocityConstraints
+    for (int i = 0; i < s.count; ++i) {
+        VConstraint& vc = s.vc[i];
+        const float mB = vc.invMassB, iB = vc.invIB;
+        const int pointCount = vc.pointCount;
+        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
+        const float friction = vc.friction;
+        for (int j = 0; j < pointCount; ++j) {
+            VCPoint& vcp = vc.points[j];
+            V2 dv = vB + cross_sv(wB, vcp.rB);
+            float vt = dot(dv, tangent) - 0.0f;
+            float lambda = vcp.tangentMass * (-vt);
+            float maxFriction = friction * vcp.normalImpulse;
+            float newImpulse = fclamp(vcp.tangentImpulse + lambda, -maxFriction, maxFriction);
+            lambda = newImpulse - vcp.tangentImpulse;
+            vcp.tangentImpulse = newImpulse;
+            V2 P = lambda * tangent;
+            vB = vB + mB * P;
+            wB += iB * cross(vcp.rB, P);
+        }
+        if (pointCount == 1) {
+            VCPoint& vcp = vc.points[0];
+            V2 dv = vB + cross_sv(wB, vcp.rB);
+            float vn = dot(dv, normal);
+            float lambda = -vcp.normalMass * (vn - vcp.velocityBias);
+            float newImpulse = fmax2(vcp.normalImpulse + lambda, 0.0f);
+            lambda = newImpulse - vcp.normalImpulse;
+            vcp.normalImpulse = newImpulse;
+            V2 P = lambda * normal;
+            vB = vB + mB * P;
+            wB += iB * cross(vcp.rB, P);
+        } else {
+            VCPoint& cp1 = vc.points[0];
+            VCPoint& cp2 = vc.points[1];
+            V2 a = mk(cp1.normalImpulse, cp2.normalImpulse);
+            V2 dv1 = vB + cross_sv(wB, cp1.rB);
+            V2 dv2 = vB + cross_sv(wB, cp2.rB);
+            float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
+            V2 b = mk(vn1 - cp1.velocityBias, vn2 - cp2.velocityBias);
+            b = b - mk(vc.k11 * a.x + vc.k12 * a.y, vc.k21 * a.x + vc.k22 * a.y);
+            for (;;) {
+                V2 x = -mk(vc.nm11 * b.x + vc.nm12 * b.y, vc.nm21 * b.x + vc.nm22 * b.y);
+                if (x.x >= 0.0f && x.y >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+                x.x = -cp1.normalMass * b.x; x.y = 0.0f;
+                vn2 = vc.k21 * x.x + b.y;
+                if (x.x >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+                x.x = 0.0f; x.y = -cp2.normalMass * b.y;
+                vn1 = vc.k12 * x.y + b.x;
+                if (x.y >= 0.0f && vn1 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+                x.x = 0.0f; x.y = 0.0f;
+                vn1 = b.x; vn2 = b.y;
+                if (vn1 >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+                break;
+            }
+        }
+        vel[vc.indexB].v = vB; vel[vc.indexB].w = wB;
+    }
+}
+
+LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::StoreImpulses
+    for (int i = 0; i < s.count; ++i) {
+        const VConstraint& vc = s.vc[i];
+        Manifold& manifold = w.ct[vc.slot].m;
+        for (int j = 0; j < vc.pointCount; ++j) {
+            manifold.points[j].normalImpulse = vc.points[j].normalImpulse;
+            manifold.points[j].tangentImpulse = vc.points[j].tangentImpulse;
+        }
+    }
+}
+
+// b2ContactSolver::SolvePositionConstraints (toi = false) / SolveTOIPositionConstraints (toi = true; the TOI
+// body is always body B of every constraint in the TOI island, so its masses are kept)
+LLD bool cs_solve_position(const CSolver& s, Pos* pos, bool toi) {
+    float minSeparation = 0.0f;
+    for (int i = 0; i < s.count; ++i) {
+        const PConstraint& pc = s.pc[i];
+        const float mB = pc.invMassB, iB = pc.invIB;
+        V2 cB = pos[pc.indexB].c; float aB = pos[pc.indexB].a;
+        for (int j = 0; j < pc.pointCount; ++j) {
+            Xf xfB;
+            xfB.q = rot_set(aB);
+            xfB.p = cB - rmul(xfB.q, pc.localCenterB);
+            V2 normal, point; float separation;
+            psm_init(pc, xfB, j, normal, point, separation);
+            V2 rB = point - cB;
+            minSeparation = fmin2(minSeparation, separation);
+            float C = fclamp((toi ? b2_toiBaumgarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
+            float rnB = cross(rB, normal);
+            float K = mB + iB * rnB * rnB;
+            float impulse = K > 0.0f ? -C / K : 0.0f;
+            V2 P = impulse * normal;
+            cB = cB + mB * P;
+            aB += iB * cross(rB, P);
+        }
+        pos[pc.indexB].c = cB; pos[pc.indexB].a = aB;
+    }
+    return toi ? (minSeparation >= -1.5f * b2_linearSlop) : (minSeparation >= -3.0f * b2_linearSlop);
+}
+
+// ---- revolute joint ---------------------------------------------------------------------------------------
+LLD void rj_init_velocity(Joint& j, int leg, const LLConst& k, const Pos* pos, Vel* vel, float dtRatio) {
+    const int ji = leg - 1;
+    float aA = pos[0].a; V2 vA = vel[0].v; float wA = vel[0].w;
+    float aB = pos[leg].a; V2 vB = vel[leg].v; float wB = vel[leg].w;
+    Rot qA = rot_set(aA), qB = rot_set(aB);
+    j.rA = rmul(qA, mk(0.0f, 0.0f) - k.localCenter[0]);
+    j.rB = rmul(qB, k.localAnchorB[ji] - k.localCenter[1]);
+    const float mA = k.invMass[0], mB = k.invMass[1], iA = k.invI[0], iB = k.invI[1];
+    j.K11 = mA + mB + j.rA.y * j.rA.y * iA + j.rB.y * j.rB.y * iB;
+    j.K12 = -j.rA.y * j.rA.x * iA - j.rB.y * j.rB.x * iB;
+    j.K21 = j.K12;
+    j.K22 = mA + mB + j.rA.x * j.rA.x * iA + j.rB.x * j.rB.x * iB;
+    j.axialMass = iA + iB;
+    j.axialMass = 1.0f / j.axialMass;  // iA + iB > 0 always
+    j.angle = aB - aA - 0.0f;          // referenceAngle = 0
+    j.impulse = dtRatio * j.impulse;
+    j.motorImpulse *= dtRatio; j.lowerImpulse *= dtRatio; j.upperImpulse *= dtRatio;
+    float axialImpulse = j.motorImpulse + j.lowerImpulse - j.upperImpulse;
+    V2 P = j.impulse;
+    vA = vA - mA * P;
+    wA -= iA * (cross(j.rA, P) + axialImpulse);
+    vB = vB + mB * P;
+    wB += iB * (cross(j.rB, P) + axialImpulse);
+    vel[0].v = vA; vel[0].w = wA; vel[leg].v = vB; vel[leg].w = wB;
+}
+
+LLD void rj_solve_velocity(Joint& j, int ji, const LLConst& k, V2& vA, float& wA, V2& vB, float& wB, float dt, float inv_dt) {
+    const float mA = k.invMass[0], mB = k.invMass[1], iA = k.invI[0], iB = k.invI[1];
+    {
+        float Cdot = wB - wA - k.motorSpeed[ji];
+        float impulse = -j.axialMass * Cdot;
+        float oldImpulse = j.motorImpulse;
+        float maxImpulse = dt * k.maxMotorTorque;
+        j.motorImpulse = fclamp(oldImpulse + impulse, -maxImpulse, maxImpulse);
+        impulse = j.motorImpulse - oldImpulse;
+        wA -= iA * impulse;
+        wB += iB * impulse;
+    }
+    {
+        float C = j.angle - k.lowerAngle[ji];
+        float Cdot = wB - wA;
+        float impulse = -j.axialMass * (Cdot + fmax2(C, 0.0f) * inv_dt);
+        float newImpulse = fmax2(j.lowerImpulse + impulse, 0.0f);
+        impulse = newImpulse - j.lowerImpulse;
+        j.lowerImpulse = newImpulse;
+        wA -= iA * impulse;
+        wB += iB * impulse;
+    }
+    {
+        float C = k.upperAngle[ji] - j.angle;
+        float Cdot = wA - wB;
+        float impulse = -j.axialMass * (Cdot + fmax2(C, 0.0f) * inv_dt);
+        float newImpulse = fmax2(j.upperImpulse + impulse, 0.0f);
+        impulse = newImpulse - j.upperImpulse;
+        j.upperImpulse = newImpulse;
+        wA += iA * impulse;
+        wB -= iB * impulse;
+    }
+    {
+        V2 Cdot = vB + cross_sv(wB, j.rB) - vA - cross_sv(wA, j.rA);
+        V2 impulse = mat22_solve(j.K11, j.K12, j.K21, j.K22, -Cdot);
+        j.impulse.x += impulse.x;
+        j.impulse.y += impulse.y;
+        vA = vA - mA * impulse;
+        wA -= iA * cross(j.rA, impulse);
+        vB = vB + mB * impulse;
+        wB += iB * cross(j.rB, impulse);
+    }
+}
+
+LLD bool rj_solve_position(const Joint& j, int ji, const LLConst& k, Pos& pA, Pos& pB) {
+    V2 cA = pA.c; float aA = pA.a; V2 cB = pB.c; float aB = pB.a;
+    float angularError = 0.0f, positionError = 0.0f;
+    const float mA = k.invMass[0], mB = k.invMass[1], iA = k.invI[0], iB = k.invI[1];
+    {
+        float angle = aB - aA - 0.0f;
+        float C = 0.0f;
+        if (fabs1(k.upperAngle[ji] - k.lowerAngle[ji]) < 2.0f * b2_angularSlop) {
+            C = fclamp(angle - k.lowerAngle[ji], -b2_maxAngularCorrection, b2_maxAngularCorrection);
+        } else if (angle <= k.lowerAngle[ji]) {
+            C = fclamp(angle - k.lowerAngle[ji] + b2_angularSlop, -b2_maxAngularCorrection, 0.0f);
+        } else if (angle >= k.upperAngle[ji]) {
+            C = fclamp(angle - k.upperAngle[ji] - b2_angularSlop, 0.0f, b2_maxAngularCorrection);
+        }
+        float limitImpulse = -j.axialMass * C;
+        aA -= iA * limitImpulse;
+        aB += iB * limitImpulse;
+        angularError = fabs1(C);
+    }
+    {
+        Rot qA = rot_set(aA), qB = rot_set(aB);
+        V2 rA = rmul(qA, mk(0.0f, 0.0f) - k.localCenter[0]);
+        V2 rB = rmul(qB, k.localAnchorB[ji] - k.localCenter[1]);
+        V2 C = cB + rB - cA - rA;
+        positionError = len(C);
+        float Kexx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+        float Kexy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+        float Keyx = Kexy;
+        float Keyy = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+        V2 impulse = -mat22_solve(Kexx, Keyx, Kexy, Keyy, C);
+        cA = cA - mA * impulse;
+        aA -= iA * cross(rA, impulse);
+        cB = cB + mB * impulse;
+        aB += iB * cross(rB, impulse);
+    }
+    pA.c = cA; pA.a = aA; pB.c = cB; pB.a = aB;
+    return positionError <= b2_linearSlop && angularError <= b2_angularSlop;
+}
+
+// ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
+LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, float inv_dt, float dtRatio) {
+    for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
+    for (int s = 0; s < kSlots; ++s) w.ct[s].islandFlag = false;
+    int seed = -1;
+    for (int i = 2; i >= 0; --i)
+        if (w.b[i].awake) { seed = i; break; }
+    if (seed < 0) return;
+
+    // depth-first search with Box2D's stack discipline (ground = 3 on the stack)
+    int ibody[3], nb = 0, icontact[kSlots], nc = 0, ijoint[2], nj = 0;
+    bool jflag[2] = {false, false}, groundFlag = false;
+    int stack[6], sc = 0;
+    int order[kSlots];
+    const int n_order = contact_order(w, order);
+    stack[sc++] = seed; w.b[seed].islandFlag = true;
+    while (sc > 0) {
+        int bi = stack[--sc];
+        if (bi == 3) continue;  // static body: in the island, not traversed, contributes nothing
+        ibody[nb++] = bi;
+        w.b[bi].awake = true;
+        for (int q = 0; q < n_order; ++q) {
+            Contact& c = w.ct[order[q]];
+            if (c.body != bi || c.islandFlag) continue;
+            if (!c.enabled || !c.touching) continue;
+            icontact[nc++] = order[q];
+            c.islandFlag = true;
+            if (groundFlag) continue;
+            stack[sc++] = 3; groundFlag = true;
+        }
+        for (int jj = 1; jj >= 0; --jj) {
+            const int leg = 1 + jj;
+            if (bi != 0 && bi != leg) continue;
+            if (jflag[jj]) continue;
+            int other = bi == 0 ? leg : 0;
+            ijoint[nj++] = jj; jflag[jj] = true;
+            if (w.b[other].islandFlag) continue;
+            stack[sc++] = other; w.b[other].islandFlag = true;
+        }
+    }
+
+    Pos pos[3]; Vel vel[3];
+    const float h = dt;
+    for (int i = 0; i < 3; ++i) {  // all three bodies are always in the island (joints connect them)
+        Body& b = w.b[i];
+        const int t = poly_of(i);
+        V2 v = b.v; float wv = b.w;
+        b.sw.c0 = b.sw.c; b.sw.a0 = b.sw.a;
+        v = v + (h * k.invMass[t]) * ((1.0f * k.mass[t]) * mk(0.0f, k.gravity) + b.force);
+        wv += h * k.invI[t] * b.torque;
+        v = (1.0f / (1.0f + h * 0.0f)) * v;
+        wv *= 1.0f / (1.0f + h * 0.0f);
+        pos[i].c = b.sw.c; pos[i].a = b.sw.a; vel[i].v = v; vel[i].w = wv;
+    }
+
+    CSolver cs;
+    cs_init(cs, w, k, icontact, nc, true, dtRatio);
+    cs_init_velocity(cs, w, pos, vel);
+    cs_warm_start(cs, vel);
+    for (int i = 0; i < nj; ++i) rj_init_velocity(w.jt[ijoint[i]], 1 + ijoint[i], k, pos, vel, dtRatio);
+    for (int it = 0; it < 180; ++it) {
+        for (int i = 0; i < nj; ++i) {
+            const int jj = ijoint[i];
+            rj_solve_velocity(w.jt[jj], jj, k, vel[0].v, vel[0].w, vel[1 + jj].v, vel[1 + jj].w, dt, inv_dt);
+        }
+        cs_solve_velocity(cs, vel);
+    }
+    cs_store_impulses(cs, w);
+
+    for (int i = 0; i < 3; ++i) {
+        V2 c = pos[i].c; float a = pos[i].a; V2 v = vel[i].v; float wv = vel[i].w;
+        V2 translation = h * v;
+        if (dot(translation, translation) > b2_maxTranslationSquared) {
+            float ratio = b2_maxTranslation / len(translation);
+            v = ratio * v;
+        }
+        float rotation = h * wv;
+        if (rotation * rotation > b2_maxRotationSquared) {
+            float ratio = b2_maxRotation / fabs1(rotation);
+            wv *= ratio;
+        }
+        c = c + h * v;
+        a += h * wv;
+        pos[i].c = c; pos[i].a = a; vel[i].v = v; vel[i].w = wv;
+    }
+
+    bool positionSolved = false;
+    for (int it = 0; it < 60; ++it) {
+        bool contactsOkay = cs_solve_position(cs, pos, false);
+        bool jointsOkay = true;
+        for (int i = 0; i < nj; ++i) {
+            const int jj = ijoint[i];
+            bool jointOkay = rj_solve_position(w.jt[jj], jj, k, pos[0], pos[1 + jj]);
+            jointsOkay = jointsOkay && jointOkay;
+        }
+        if (contactsOkay && jointsOkay) { positionSolved = true; break; }
+    }
+
+    for (int i = 0; i < 3; ++i) {
+        Body& b = w.b[i];
+        b.sw.c = pos[i].c; b.sw.a = pos[i].a; b.v = vel[i].v; b.w = vel[i].w;
+        body_sync_transform(b);
+    }
+
+    float minSleepTime = FLT_MAX;
+    const float linTolSqr = b2_linearSleepTolerance * b2_linearSleepTolerance;
+    const float angTolSqr = b2_angularSleepTolerance * b2_angularSleepTolerance;
+    for (int q = 0; q < nb; ++q) {
+        Body& b = w.b[ibody[q]];
+        if (b.w * b.w > angTolSqr || dot(b.v, b.v) > linTolSqr) {
+            b.sleepTime = 0.0f;
+            minSleepTime = 0.0f;
+        } else {
+            b.sleepTime += h;
+            minSleepTime = fmin2(minSleepTime, b.sleepTime);
+        }
+    }
+    if (minSleepTime >= b2_timeToSleep && positionSolved)
+        for (int i = 0; i < 3; ++i) body_set_awake(w.b[i], false);
+
+    int moved[3], nm = 0;
+    for (int i = 2; i >= 0; --i)  // body list order: newest first
+        if (body_sync_fixtures(w, tab, i)) moved[nm++] = i;
+    find_new_contacts(w, moved, nm);
+}
+
+// ---- b2World::SolveTOI ----------------------------------------------------------------------------------
+LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, float dt) {
+    for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
+    bool any = false;
+    for (int s = 0; s < kSlots; ++s) {
+        Contact& c = w.ct[s];
+        if (!c.exists) continue;
+        any = true;
+        c.toiFlag = false; c.islandFlag = false; c.toiCount = 0; c.toi = 1.0f;
+    }
+    if (!any) return;
+    float gA = 0.0f;  // alpha0 of the static ground's sweep (its c0/a0 never move; only alpha0 ratchets)
+    for (;;) {
+        int minSlot = -1;
+        float minAlpha = 1.0f;
+        int order[kSlots];
+        const int n_order = contact_order(w, order);
+        for (int q = 0; q < n_order; ++q) {
+            Contact& c = w.ct[order[q]];
+            if (!c.enabled) continue;
+            if (c.toiCount > b2_maxSubSteps) continue;
+            float alpha = 1.0f;
+            if (c.toiFlag) {
+                alpha = c.toi;
+            } else {
+                Body& bB = w.b[c.body];
+                if (!bB.awake) continue;
+                // put the sweeps onto the same time interval (the shared static body carries an alpha0 too)
+                float alpha0 = gA;
+                if (gA < bB.sw.alpha0) { alpha0 = bB.sw.alpha0; gA = alpha0; }
+                else if (bB.sw.alpha0 < gA) { alpha0 = gA; sweep_advance(bB.sw, alpha0); }
+                V2 ev[2];
+                edge_verts(w, c.edge, ev[0], ev[1]);
+                float beta;
+                int state = time_of_impact(ev, tab, poly_of(c.body), bB.sw, beta);
+                if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+                else alpha = 1.0f;
+                c.toi = alpha;
+                c.toiFlag = true;
+            }
+            if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
+        }
+        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) break;
+
+        Contact& minContact = w.ct[minSlot];
+        const int dyn = minContact.body;
+        Body& bB = w.b[dyn];
+        Sweep backup = bB.sw;
+        const float gA_backup = gA;
+        gA = minAlpha;  // bA->Advance(minAlpha) on the ground
+        body_advance(bB, minAlpha);
+        contact_update(w, tab, minContact);
+        minContact.toiFlag = false;
+        ++minContact.toiCount;
+        if (!minContact.enabled || !minContact.touching) {
+            minContact.enabled = false;
+            bB.sw = backup;
+            gA = gA_backup;
+            body_sync_transform(bB);
+            continue;
+        }
+        body_set_awake(bB, true);
+
+        int islandSlots[kSlots], nc = 0;
+        islandSlots[nc++] = minSlot;
+        minContact.islandFlag = true;
+        for (int q = 0; q < n_order; ++q) {
+            Contact& c = w.ct[order[q]];
+            if (!c.exists || c.body != dyn || c.islandFlag) continue;
+            contact_update(w, tab, c);
+            if (!c.enabled || !c.touching) continue;
+            c.islandFlag = true;
+            islandSlots[nc++] = order[q];
+        }
+
+        // b2Island::SolveTOI: positions/velocities of the one dynamic body (slot `dyn` of a 3-entry table)
+        const float sub_dt = (1.0f - minAlpha) * dt;
+        Pos pos[3]; Vel vel[3];
+        pos[dyn].c = bB.sw.c; pos[dyn].a = bB.sw.a; vel[dyn].v = bB.v; vel[dyn].w = bB.w;
+        CSolver cs;
+        cs_init(cs, w, k, islandSlots, nc, false, 1.0f);
+        for (int i = 0; i < 20; ++i)
+            if (cs_solve_position(cs, pos, true)) break;
+        bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
+        cs_init_velocity(cs, w, pos, vel);
+        for (int i = 0; i < 180; ++i) cs_solve_velocity(cs, vel);
+        {
+            const float h = sub_dt;
+            V2 c = pos[dyn].c; float a = pos[dyn].a; V2 v = vel[dyn].v; float wv = vel[dyn].w;
+            V2 translation = h * v;
+            if (dot(translation, translation) > b2_maxTranslationSquared) {
+                float ratio = b2_maxTranslation / len(translation);
+                v = ratio * v;
+            }
+            float rotation = h * wv;
+            if (rotation * rotation > b2_maxRotationSquared) {
+                float ratio = b2_maxRotation / fabs1(rotation);
+                wv *= ratio;
+            }
+            c = c + h * v;
+            a += h * wv;
+            bB.sw.c = c; bB.sw.a = a; bB.v = v; bB.w = wv;
+            body_sync_transform(bB);
+        }
+        int moved[1], nm = 0;
+        if (body_sync_fixtures(w, tab, dyn)) moved[nm++] = dyn;
+        for (int s = 0; s < kSlots; ++s)
+            if (w.ct[s].exists && w.ct[s].body == dyn) { w.ct[s].toiFlag = false; w.ct[s].islandFlag = false; }
+        find_new_contacts(w, moved, nm);
+    }
+}
+
+// b2World::Step(1/50, 180, 60)
+LLD void world_step(World& w, const PolyTab& tab, const LLConst& k) {
+    if (w.newContacts) {
+        int order[3], n = 0;
+        for (int i = 0; i < 3; ++i)
+            if (w.pending & (1u << i)) order[n++] = i;
+        find_new_contacts(w, order, n);
+        w.pending = 0;
+        w.newContacts = false;
+    }
+    const float dt = 1.0f / 50.0f;
+    const float inv_dt = 1.0f / dt;
+    const float dtRatio = (w.stepped_once ? inv_dt : 0.0f) * dt;
+    collide(w, tab);
+    solve_island(w, tab, k, dt, inv_dt, dtRatio);
+    solve_toi(w, tab, k, dt);
+    w.stepped_once = true;
+    for (int i = 0; i < 3; ++i) { w.b[i].force = mk(0.0f, 0.0f); w.b[i].torque = 0.0f; }
+}
+
+}  // namespace ll
+}  // namespace mgym

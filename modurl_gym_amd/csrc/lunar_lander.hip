@@ -1,3 +1,216 @@
-// placeholder until the LunarLander kernels land
+// lunar_lander.hip — LunarLanderV3 step()/reset() as gfx950 kernels, one wavefront lane per environment.
+//
+// Replaces the bodies of `impl Gym for LunarLanderV3` (reference src/box_2d/lunar_lander.rs: reset
+// :727-917, step :919-1167) and the box2d-rs world it drives (ll_b2.h / ll_world.h restate Box2D).
+//
+// Data layout in HBM (engine-owned SoA, column stride n_pad words; 195 state columns + 8 observation
+// columns, ~0.8 KB per env; see enum Col):
+//   3 bodies x {xf.p, sweep.c, angle, v, w, sleepTime}; 2 joints x {impulse.xy, motor, lower, upper};
+//   3 fat AABBs; terrain smooth_y[11]; prev_shaping; flag word; wind/torque indices; step/episode
+//   counters (Philox slots); 8 contact-cache slots x 16 words (loaded only when the env has contacts).
+// Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
+// per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
+#include <math.h>
+#include <string.h>
+
 #include "common.h"
-namespace mgym { Env* make_lunarlander() { return nullptr; } }
+#include "ll_env.h"
+
+namespace mgym {
+
+
+__device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
+    if (threadIdx.x < 2 * kMaxPoly) {
+        int p = threadIdx.x / kMaxPoly, q = threadIdx.x % kMaxPoly;
+        tab.v[p][q] = k.poly_v[p][q];
+        tab.n[p][q] = k.poly_n[p][q];
+    }
+    if (threadIdx.x < 2) tab.count[threadIdx.x] = k.poly_count[threadIdx.x];
+    __syncthreads();
+}
+
+constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
+
+__global__ void __launch_bounds__(kLLBlock)
+ll_step_kernel(LLDev d, const uint32_t* __restrict__ act, float* __restrict__ obs_out, float* __restrict__ rew,
+               uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    __shared__ PolyTab tab;
+    stage_tab(tab, d.k);
+    bool not_reset = false, overflow = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        World w; EnvRegs e;
+        ll_load(d, i, w, e);
+        if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+            not_reset = true;
+            if (rew) rew[i] = 0.0f;
+            if (done_out) done_out[i] = 0;
+            if (trunc_out) trunc_out[i] = 0;
+            continue;
+        }
+        float state[8], reward, d0, d1; uint32_t done;
+        ll_dispersion(d, i, e, d0, d1);
+        ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
+        if (rew) rew[i] = reward;
+        if (done_out) done_out[i] = (uint8_t)done;
+        if (trunc_out) trunc_out[i] = 0;  // :1165 truncated: false
+        if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, state);
+        overflow |= w.overflow;
+        ll_store(d, i, w, e);
+        for (int q = 0; q < 8; ++q) {
+            d.obs[(uint64_t)q * d.n_pad + i] = state[q];
+            if (obs_out) obs_out[(uint64_t)q * d.n + i] = state[q];
+        }
+    }
+    if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
+    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+}
+
+// mode 0: reset() for masked envs; mode 1: Testable::reset_deterministic (lunar_lander.rs:1249-1442) for all
+__global__ void __launch_bounds__(kLLBlock)
+ll_reset_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int all, int mode, float* __restrict__ obs_out) {
+    __shared__ PolyTab tab;
+    stage_tab(tab, d.k);
+    bool overflow = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        bool m = all;
+        if (!all) m = (m0 && m0[i]) || (m1 && m1[i]);
+        if (!m) continue;
+        World w; EnvRegs e;
+        ll_load(d, i, w, e);
+        float state[8];
+        if (mode == 0) {
+            ll_env_reset(d, i, w, e, tab, state);
+        } else {
+            const float H = VIEWPORT_H / SCALE;
+            float height[12];
+            for (int q = 0; q < 12; ++q) height[q] = H / 8.0f;  // :1278-1280
+            ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
+            e.step = 1u;
+            ll_observe(w, state);  // :1441
+        }
+        overflow |= w.overflow;
+        ll_store(d, i, w, e);
+        for (int q = 0; q < 8; ++q) {
+            d.obs[(uint64_t)q * d.n_pad + i] = state[q];
+            if (obs_out) obs_out[(uint64_t)q * d.n + i] = state[q];
+        }
+    }
+    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+}
+
+// state blob (27 columns, identical to the CPU oracle's): raw {x,y,angle,vx,vy,w} of lander, leg0, leg1;
+// leg0_contact, leg1_contact, game_over, lander awake, prev_shaping (NaN = None), wind_idx, torque_idx,
+// step counter, episode counter.
+__global__ void ll_export_kernel(LLDev d, uint32_t* __restrict__ blob) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    const uint32_t flags = ST(C_FLAGS);
+    for (int b = 0; b < 3; ++b) {
+        const int c = C_BODY + 9 * b;
+        blob[(uint64_t)(6 * b + 0) * d.n + i] = ST(c + 0); blob[(uint64_t)(6 * b + 1) * d.n + i] = ST(c + 1);
+        blob[(uint64_t)(6 * b + 2) * d.n + i] = ST(c + 4);
+        blob[(uint64_t)(6 * b + 3) * d.n + i] = ST(c + 5); blob[(uint64_t)(6 * b + 4) * d.n + i] = ST(c + 6);
+        blob[(uint64_t)(6 * b + 5) * d.n + i] = ST(c + 7);
+    }
+    blob[18 * d.n + i] = as_u32((flags & F_LEG0) ? 1.0f : 0.0f);
+    blob[19 * d.n + i] = as_u32((flags & F_LEG1) ? 1.0f : 0.0f);
+    blob[20 * d.n + i] = as_u32((flags & F_GAME_OVER) ? 1.0f : 0.0f);
+    blob[21 * d.n + i] = as_u32((flags & 1u) ? 1.0f : 0.0f);
+    blob[22 * d.n + i] = (flags & F_PREV_SOME) ? ST(C_PREV) : 0x7fc00000u;
+    blob[23 * d.n + i] = ST(C_WIND); blob[24 * d.n + i] = ST(C_TORQUE);
+    blob[25 * d.n + i] = ST(C_STEP); blob[26 * d.n + i] = ST(C_EPISODE);
+}
+
+// Testable::set_state (lunar_lander.rs:1444-1554) from blob words 0..19; counters from 25, 26
+__global__ void __launch_bounds__(kLLBlock) ll_import_kernel(LLDev d, const uint32_t* __restrict__ blob) {
+    __shared__ PolyTab tab;
+    stage_tab(tab, d.k);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    World w; EnvRegs e;
+    ll_load(d, i, w, e);
+    if (e.has_world) {
+        float raw[18];
+        for (int q = 0; q < 18; ++q) raw[q] = as_f32(blob[(uint64_t)q * d.n + i]);
+        ll_apply_set_state(w, tab, raw, as_f32(blob[18 * d.n + i]) > 0.5f, as_f32(blob[19 * d.n + i]) > 0.5f);
+    }
+    e.step = blob[25 * d.n + i];
+    e.episode = blob[26 * d.n + i];
+    ll_store(d, i, w, e);
+}
+
+struct LunarLanderEnv final : Env {
+    void* base = nullptr;
+    void* obs_base = nullptr;
+    LLDev dev{};
+
+    ~LunarLanderEnv() override {
+        if (base) (void)hipFree(base);
+        if (obs_base) (void)hipFree(obs_base);
+    }
+
+    int init() override {
+        obs_dim = 8;
+        state_cols = 27;
+        MGYM_HIP(hipMalloc(&base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
+        MGYM_HIP(hipMemsetAsync(base, 0, (size_t)C_COUNT * n_pad * sizeof(uint32_t), stream));  // has_world = false
+        MGYM_HIP(hipMalloc(&obs_base, (size_t)8 * n_pad * sizeof(float)));
+        MGYM_HIP(hipMemsetAsync(obs_base, 0, (size_t)8 * n_pad * sizeof(float), stream));
+        dev.st = static_cast<uint32_t*>(base);
+        dev.obs = static_cast<float*>(obs_base);
+        dev.disp = nullptr;
+        dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err;
+        dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
+        ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
+        return MGYM_OK;
+    }
+
+    dim3 grid() const {
+        uint64_t b = (n + kLLBlock - 1) / kLLBlock;
+        if (b > 65536) b = 65536;
+        return dim3((unsigned)(b ? b : 1));
+    }
+
+    int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) override {
+        if (n == 0) return MGYM_OK;
+        hipLaunchKernelGGL(ll_reset_kernel, grid(), dim3(kLLBlock), 0, stream, dev, m0, m1, all ? 1 : 0, 0, obs_out);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+    int reset_deterministic(float* obs_out) override {
+        if (n == 0) return MGYM_OK;
+        hipLaunchKernelGGL(ll_reset_kernel, grid(), dim3(kLLBlock), 0, stream, dev, (const uint8_t*)nullptr, (const uint8_t*)nullptr, 1, 1, obs_out);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+    int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0) return MGYM_OK;
+        hipLaunchKernelGGL(ll_step_kernel, grid(), dim3(kLLBlock), 0, stream, dev, static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+    int observation(const float** obs, uint64_t* col_stride) override {
+        *obs = dev.obs; *col_stride = n_pad;
+        return MGYM_OK;
+    }
+    int get_state(void* blob) override {
+        if (n == 0) return MGYM_OK;
+        hipLaunchKernelGGL(ll_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dev, static_cast<uint32_t*>(blob));
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+    int set_state(const void* blob) override {
+        if (n == 0) return MGYM_OK;
+        hipLaunchKernelGGL(ll_import_kernel, dim3((unsigned)((n + kLLBlock - 1) / kLLBlock)), dim3(kLLBlock), 0, stream, dev, static_cast<const uint32_t*>(blob));
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+    int set_dispersion(const float* disp) override {
+        dev.disp = disp;
+        return MGYM_OK;
+    }
+};
+
+Env* make_lunarlander() { return new LunarLanderEnv(); }
+
+}  // namespace mgym

@@ -237,6 +237,13 @@ struct MountainCarEnv final : Env {
         return MGYM_OK;
     }
 
+    int reset_deterministic(float* obs_out) override {  // mountain_car.rs:403-408: state = zeros (no reset())
+        if (n == 0) return MGYM_OK;
+        MGYM_HIP(hipMemsetAsync(dev.pos, 0, 2 * n_pad * sizeof(float), stream));
+        if (obs_out) MGYM_HIP(hipMemsetAsync(obs_out, 0, 2 * n * sizeof(float), stream));
+        return MGYM_OK;
+    }
+
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
         const uint32_t* act = static_cast<const uint32_t*>(actions);

@@ -224,6 +224,13 @@ class VecEnv:
         self.sync()
         return self._host("obs", (self.obs_dim, self.n))
 
+    def reset_deterministic(self):
+        """Testable::reset_deterministic of the reference's test modules, on every env."""
+        b = self._buffers()
+        _check(self._lib.mgym_reset_deterministic(self._h, b["obs"].ptr))
+        self.sync()
+        return self._host("obs", (self.obs_dim, self.n))
+
     def step(self, actions):
         b = self._buffers()
         a = np.ascontiguousarray(actions, self.action_dtype)

@@ -1,0 +1,93 @@
+// CPU check of the LunarLander KERNEL SOURCE (modurl_gym_amd/csrc/ll_*.h compiled for the host through a
+// small shim) against the CPU oracle: same seeds, actions and dispersion, step by step.  Built and run by
+// tests/test_ll_host.py; no GPU involved.  This is a test of the kernel logic, not a product CPU path.
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#include "../../modurl_gym_amd/csrc/ll_env.h"
+extern "C" {
+#include "../../oracle/oracle.h"
+}
+using namespace mgym;
+
+static bool closef(float a, float b) { return fabsf(a - b) <= 1e-5f * fmaxf(fabsf(a), fabsf(b)) + 1e-6f || (a != a && b != b); }
+
+int main(int argc, char** argv) {
+    const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 0) : 64;
+    const int steps = argc > 2 ? atoi(argv[2]) : 300;
+    const int wind = argc > 3 ? atoi(argv[3]) : 0;
+    const int deterministic = argc > 4 ? atoi(argv[4]) : 0;
+    const uint64_t seed = 77;
+    // product side: SoA state exactly as the kernels keep it
+    LLDev d;
+    memset(&d, 0, sizeof d);
+    d.n = n; d.n_pad = (n + 1023) / 1024 * 1024; d.seed = seed; d.env_id_base = 0;
+    std::vector<uint32_t> st((size_t)C_COUNT * d.n_pad, 0u);
+    std::vector<float> obsbuf((size_t)8 * d.n_pad, 0.0f);
+    d.st = st.data(); d.obs = obsbuf.data();
+    ll_make_const(d.k, -10.0f, wind, 15.0f, 1.5f);
+    PolyTab tab;
+    for (int p = 0; p < 2; ++p) { tab.count[p] = d.k.poly_count[p]; for (int q = 0; q < kMaxPoly; ++q) { tab.v[p][q] = d.k.poly_v[p][q]; tab.n[p][q] = d.k.poly_n[p][q]; } }
+    // oracle side
+    ora_vec_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.kind = 3; cfg.n_envs = n; cfg.seed = seed; cfg.gravity = -10.0f; cfg.enable_wind = wind; cfg.wind_power = 15.0f; cfg.turbulence_power = 1.5f;
+    int status = 0;
+    ora_vec* ov = ora_vec_new(&cfg, &status);
+    std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
+    std::vector<uint32_t> act(n);
+    if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
+    int max_slots = 0; unsigned long hist[kSlots + 1] = {0};
+    unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        World w; EnvRegs e; float state[8];
+        ll_load(d, i, w, e);
+        if (deterministic) {
+            float height[12]; for (int q = 0; q < 12; ++q) height[q] = (400.0f / 30.0f) / 8.0f;
+            ll_build_scene(w, e, tab, d.k, height, 400.0f / 30.0f * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
+            e.step = 1u; ll_observe(w, state);
+        } else ll_env_reset(d, i, w, e, tab, state);
+        ll_store(d, i, w, e);
+        for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; if (!closef(state[q], oobs[q * n + i])) { if (mism < 10) printf("reset env %lu obs[%d] %.9g vs %.9g\n", (unsigned long)i, q, state[q], oobs[q * n + i]); mism++; } }
+    }
+    uint32_t rs = 12345;
+    for (int t = 0; t < steps; ++t) {
+        for (uint64_t i = 0; i < n; ++i) { rs = rs * 1664525u + 1013904223u; act[i] = (rs >> 16) & 3u; }
+        ora_vec_step(ov, act.data(), oobs.data(), orew.data(), odone.data(), otr.data(), 1);
+        for (uint64_t i = 0; i < n; ++i) {
+            World w; EnvRegs e; float state[8], reward, d0, d1; uint32_t done;
+            ll_load(d, i, w, e);
+            ll_dispersion(d, i, e, d0, d1);
+            ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
+            if (w.overflow) overflow++;
+            { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
+            ll_store(d, i, w, e);
+            bool bad = done != odone[i] || !closef(reward, orew[i]);
+            for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; bad |= !closef(state[q], oobs[q * n + i]); }
+            if (bad) {
+                if (mism < 10) {
+                    printf("step %d env %lu act %u: done %u vs %u reward %.9g vs %.9g\n", t, (unsigned long)i, act[i], done, odone[i], reward, orew[i]);
+                    for (int q = 0; q < 8; ++q) printf("   obs[%d] %.9g vs %.9g\n", q, state[q], oobs[q * n + i]);
+                }
+                mism++;
+            }
+            mask[i] = odone[i]; done_total += odone[i];
+        }
+        if (t % 2 == 0 && !deterministic) {  // masked reset of finished envs on both sides
+            ora_vec_reset(ov, mask.data(), NULL, 1);
+            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e); ll_env_reset(d, i, w, e, tab, state); ll_store(d, i, w, e); }
+        }
+    }
+    printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
+    printf("max simultaneous cached contacts %d; histogram:", max_slots);
+    for (int q = 0; q <= kSlots; ++q) printf(" %lu", hist[q]);
+    printf("\n");
+    ora_vec_free(ov);
+    return mism ? 1 : 0;
+}
