@@ -41,6 +41,8 @@ struct LLDev {
     const float* disp;  // dispersion override [2][n] or nullptr
     uint64_t n, n_pad, seed, env_id_base;
     uint32_t* err;
+    uint32_t* work_list;   // compacted env indices for the general kernel (n words)
+    uint32_t* work_count;
     LLConst k;
     int auto_reset;
 };
@@ -193,8 +195,7 @@ __device__ __forceinline__ void apply_linear_impulse(Body& b, const LLConst& k, 
 }
 
 // observation, lunar_lander.rs:1095-1121
-__device__ __forceinline__ void ll_observe(const World& w, float state[8]) {
-    const Body& lander = w.b[0];
+__device__ __forceinline__ void ll_observe(const Body& lander, bool leg0, bool leg1, float state[8]) {
     V2 pos = lander.xf.p, vel = lander.v;
     const float helipad_y = (VIEWPORT_H / SCALE) / 4.0f;
     state[0] = (pos.x - VIEWPORT_W / SCALE / 2.0f) / (VIEWPORT_W / SCALE / 2.0f);
@@ -203,16 +204,15 @@ __device__ __forceinline__ void ll_observe(const World& w, float state[8]) {
     state[3] = vel.y * (VIEWPORT_H / SCALE / 2.0f) / FPS;
     state[4] = lander.sw.a;
     state[5] = 20.0f * lander.w / FPS;
-    state[6] = w.legs[0] ? 1.0f : 0.0f;
-    state[7] = w.legs[1] ? 1.0f : 0.0f;
+    state[6] = leg0 ? 1.0f : 0.0f;
+    state[7] = leg1 ? 1.0f : 0.0f;
 }
 
-// step(), lunar_lander.rs:919-1167.  disp = the two raw U(-1,1) draws of :973-974.
-__device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, uint32_t action, float disp0, float disp1,
-                            float state[8], float& reward, uint32_t& done) {
-    Body& lander = w.b[0];
+// step() before the world step: wind and engine impulses on the lander, lunar_lander.rs:926-1048
+__device__ __forceinline__ void ll_pre_step(Body& lander, bool leg0, bool leg1, EnvRegs& e, const LLConst& k, uint32_t action, float disp0,
+                                            float disp1, float& m_power, float& s_power) {
     if (k.enable_wind) {  // :927-959
-        bool legs_contact = w.legs[0] || w.legs[1];
+        bool legs_contact = leg0 || leg1;
         if (!legs_contact) {
             float wind_mag = mg_tanhf(mg_sinf(0.02f * (float)e.wind_idx) + mg_sinf(PI_F32 * 0.01f * (float)e.wind_idx)) * k.wind_power;
             e.wind_idx += 1;
@@ -229,7 +229,7 @@ __device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLCo
     if (e.deterministic) { dispersion0 = 0.0f; dispersion1 = 0.0f; }
     else { dispersion0 = disp0 / SCALE; dispersion1 = disp1 / SCALE; }
 
-    float m_power = 0.0f;
+    m_power = 0.0f;
     if (action == 2u) {  // :979-1003
         m_power = 1.0f;
         V2 lander_pos = lander.xf.p;
@@ -239,7 +239,7 @@ __device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLCo
         V2 impulse_force = mk(-ox * MAIN_ENGINE_POWER * m_power, -oy * MAIN_ENGINE_POWER * m_power);
         apply_linear_impulse(lander, k, impulse_force, impulse_pos);
     }
-    float s_power = 0.0f;
+    s_power = 0.0f;
     if (action == 1u || action == 3u) {  // :1019-1048
         float direction = (float)((int32_t)action - 2);
         s_power = 1.0f;
@@ -250,10 +250,12 @@ __device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLCo
         V2 impulse_force = mk(-ox * SIDE_ENGINE_POWER * s_power, -oy * SIDE_ENGINE_POWER * s_power);
         apply_linear_impulse(lander, k, impulse_force, impulse_pos);
     }
+}
 
-    world_step(w, tab, k);  // :1066
-
-    ll_observe(w, state);
+// step() after the world step: observation, shaping reward, termination, lunar_lander.rs:1094-1167
+__device__ __forceinline__ void ll_post_step(const Body& lander, bool game_over, bool leg0, bool leg1, EnvRegs& e, float m_power, float s_power,
+                                             float state[8], float& reward, uint32_t& done) {
+    ll_observe(lander, leg0, leg1, state);
     reward = 0.0f;  // :1126-1139
     float shaping = -100.0f * sqrtf(state[0] * state[0] + state[1] * state[1]) -
                     100.0f * sqrtf(state[2] * state[2] + state[3] * state[3]) - 100.0f * fabsf(state[4]) +
@@ -263,9 +265,18 @@ __device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLCo
     reward -= m_power * 0.30f;
     reward -= s_power * 0.03f;
     done = 0u;  // :1142-1156
-    if (w.game_over || fabsf(state[0]) >= 1.0f) { done = 1u; reward = -100.0f; }
+    if (game_over || fabsf(state[0]) >= 1.0f) { done = 1u; reward = -100.0f; }
     else if (!lander.awake) { done = 1u; reward = 100.0f; }
     e.step += 1u;
+}
+
+// step(), lunar_lander.rs:919-1167.  disp = the two raw U(-1,1) draws of :973-974.
+__device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, uint32_t action, float disp0, float disp1,
+                            float state[8], float& reward, uint32_t& done) {
+    float m_power, s_power;
+    ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, k, action, disp0, disp1, m_power, s_power);
+    world_step(w, tab, k);  // :1066
+    ll_post_step(w.b[0], w.game_over, w.legs[0], w.legs[1], e, m_power, s_power, state, reward, done);
 }
 
 // world/terrain/lander/legs construction shared by reset() (:733-908) and reset_deterministic() (:1256-1438)

@@ -1,0 +1,201 @@
+// ll_free.h — contact-free fast path of the LunarLander step.
+//
+// Most environment-steps are free flight: no cached ground contact, all three bodies awake.  For those,
+// b2World::Step (ll_world.h) reduces to: integrate velocities -> 180 sweeps over the two revolute joints
+// -> integrate positions -> a few joint position iterations -> sleep bookkeeping -> fat-AABB update.
+// This file restates exactly that reduced step with every quantity in VGPRs (no contact cache, no local
+// arrays), using the SAME primitives as the general path (rj_*, integrate_*, sleep_update, fixture_sync),
+// in the same order, so results are bit-identical to world_step().  It never creates a contact: if the
+// updated fat AABBs start to overlap a ground edge (or any other precondition fails) it reports `false`
+// and the caller hands the untouched environment to the general kernel through the worklist.
+#pragma once
+#include "ll_env.h"
+
+namespace mgym {
+
+// columns a contact-free environment needs (no contact slots, no terrain unless a proxy moved)
+struct FreeRegs {
+    Body b[3];
+    Joint jt[2];
+    AABB fat[3];
+    uint32_t flags;
+};
+
+__device__ __forceinline__ void ll_free_load(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e) {
+    const uint32_t flags = ST(C_FLAGS);
+    f.flags = flags;
+    for (int b = 0; b < 3; ++b) {
+        Body& bd = f.b[b];
+        const int c = C_BODY + 9 * b;
+        bd.xf.p = mk(as_f32(ST(c + 0)), as_f32(ST(c + 1)));
+        bd.sw.c = mk(as_f32(ST(c + 2)), as_f32(ST(c + 3)));
+        bd.sw.a = as_f32(ST(c + 4));
+        bd.v = mk(as_f32(ST(c + 5)), as_f32(ST(c + 6)));
+        bd.w = as_f32(ST(c + 7));
+        bd.sleepTime = as_f32(ST(c + 8));
+        bd.sw.localCenter = d.k.localCenter[b == 0 ? 0 : 1];
+        bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a; bd.sw.alpha0 = 0.0f;
+        bd.force = mk(0.0f, 0.0f); bd.torque = 0.0f;
+        bd.awake = true; bd.islandFlag = false;
+        f.fat[b].lo = mk(as_f32(ST(C_FAT + 4 * b + 0)), as_f32(ST(C_FAT + 4 * b + 1)));
+        f.fat[b].hi = mk(as_f32(ST(C_FAT + 4 * b + 2)), as_f32(ST(C_FAT + 4 * b + 3)));
+    }
+    for (int j = 0; j < 2; ++j) {
+        const int c = C_JOINT + 5 * j;
+        f.jt[j].impulse = mk(as_f32(ST(c + 0)), as_f32(ST(c + 1)));
+        f.jt[j].motorImpulse = as_f32(ST(c + 2));
+        f.jt[j].lowerImpulse = as_f32(ST(c + 3));
+        f.jt[j].upperImpulse = as_f32(ST(c + 4));
+    }
+    e.prev_shaping = as_f32(ST(C_PREV));
+    e.prev_some = flags & F_PREV_SOME;
+    e.wind_idx = (int32_t)ST(C_WIND); e.torque_idx = (int32_t)ST(C_TORQUE);
+    e.step = ST(C_STEP); e.episode = ST(C_EPISODE);
+    e.has_world = true;
+    e.deterministic = flags & F_DETERMINISTIC;
+}
+
+__device__ __forceinline__ void ll_free_store(const LLDev& d, uint64_t i, const FreeRegs& f, const EnvRegs& e) {
+    uint32_t flags = f.flags & (F_GAME_OVER | F_LEG0 | F_LEG1 | F_HAS_WORLD | F_DETERMINISTIC);
+    for (int b = 0; b < 3; ++b) {
+        const Body& bd = f.b[b];
+        const int c = C_BODY + 9 * b;
+        ST(c + 0) = as_u32(bd.xf.p.x); ST(c + 1) = as_u32(bd.xf.p.y);
+        ST(c + 2) = as_u32(bd.sw.c.x); ST(c + 3) = as_u32(bd.sw.c.y);
+        ST(c + 4) = as_u32(bd.sw.a);
+        ST(c + 5) = as_u32(bd.v.x); ST(c + 6) = as_u32(bd.v.y);
+        ST(c + 7) = as_u32(bd.w);
+        ST(c + 8) = as_u32(bd.sleepTime);
+        if (bd.awake) flags |= 1u << b;
+        ST(C_FAT + 4 * b + 0) = as_u32(f.fat[b].lo.x); ST(C_FAT + 4 * b + 1) = as_u32(f.fat[b].lo.y);
+        ST(C_FAT + 4 * b + 2) = as_u32(f.fat[b].hi.x); ST(C_FAT + 4 * b + 3) = as_u32(f.fat[b].hi.y);
+    }
+    for (int j = 0; j < 2; ++j) {
+        const int c = C_JOINT + 5 * j;
+        ST(c + 0) = as_u32(f.jt[j].impulse.x); ST(c + 1) = as_u32(f.jt[j].impulse.y);
+        ST(c + 2) = as_u32(f.jt[j].motorImpulse); ST(c + 3) = as_u32(f.jt[j].lowerImpulse); ST(c + 4) = as_u32(f.jt[j].upperImpulse);
+    }
+    flags |= F_STEPPED | (e.prev_some ? F_PREV_SOME : 0u);  // newContacts = false, pending = 0, no contacts
+    ST(C_FLAGS) = flags;
+    ST(C_PREV) = as_u32(e.prev_shaping);
+    ST(C_WIND) = (uint32_t)e.wind_idx; ST(C_TORQUE) = (uint32_t)e.torque_idx;
+    ST(C_STEP) = e.step; ST(C_EPISODE) = e.episode;
+}
+
+// fat AABB of ground edge `e` of env i, terrain read from HBM on demand (same arithmetic as edge_fat)
+__device__ __forceinline__ AABB ll_edge_fat_global(const LLDev& d, uint64_t i, int e) {
+    V2 v1, v2;
+    if (e == 0) { v1 = mk(0.0f, 0.0f); v2 = mk(kW, 0.0f); }
+    else {
+        const float cw = kW / 10.0f;
+        v1 = mk(cw * (float)(e - 1), as_f32(ST(C_SMOOTH + e - 1)));
+        v2 = mk(cw * (float)e, as_f32(ST(C_SMOOTH + e)));
+    }
+    V2 lower = mk(fmin2(v1.x, v2.x), fmin2(v1.y, v2.y)), upper = mk(fmax2(v1.x, v2.x), fmax2(v1.y, v2.y));
+    AABB a;
+    a.lo = mk((lower.x - b2_polygonRadius) - b2_aabbExtension, (lower.y - b2_polygonRadius) - b2_aabbExtension);
+    a.hi = mk((upper.x + b2_polygonRadius) + b2_aabbExtension, (upper.y + b2_polygonRadius) + b2_aabbExtension);
+    return a;
+}
+__device__ __forceinline__ bool ll_any_ground_overlap(const LLDev& d, uint64_t i, AABB box) {
+    for (int e = 0; e < kEdges; ++e)
+        if (aabb_overlap(box, ll_edge_fat_global(d, i, e))) return true;
+    return false;
+}
+
+// eligibility from the flag word alone: world exists, all three bodies awake, no cached contacts
+__device__ __forceinline__ bool ll_free_eligible(uint32_t flags) {
+    return (flags & F_HAS_WORLD) && ((flags & 7u) == 7u) && (((flags >> F_NCONTACT_SHIFT) & 15u) == 0u);
+}
+
+// MoveProxy on a register-resident fat AABB (same rule as move_proxy in ll_world.h)
+__device__ __forceinline__ bool ll_free_move_proxy(AABB& tree, AABB aabb, V2 displacement) {
+    AABB fatAABB;
+    fatAABB.lo = mk(aabb.lo.x - b2_aabbExtension, aabb.lo.y - b2_aabbExtension);
+    fatAABB.hi = mk(aabb.hi.x + b2_aabbExtension, aabb.hi.y + b2_aabbExtension);
+    V2 dd = b2_aabbMultiplier * displacement;
+    if (dd.x < 0.0f) fatAABB.lo.x += dd.x; else fatAABB.hi.x += dd.x;
+    if (dd.y < 0.0f) fatAABB.lo.y += dd.y; else fatAABB.hi.y += dd.y;
+    if (aabb_contains(tree, aabb)) {
+        AABB huge;
+        huge.lo = mk(fatAABB.lo.x - 4.0f * b2_aabbExtension, fatAABB.lo.y - 4.0f * b2_aabbExtension);
+        huge.hi = mk(fatAABB.hi.x + 4.0f * b2_aabbExtension, fatAABB.hi.y + 4.0f * b2_aabbExtension);
+        if (aabb_contains(huge, tree)) return false;
+    }
+    tree = fatAABB;
+    return true;
+}
+
+// One full Gym::step of a contact-free environment.  Returns false (nothing may be stored) when the env
+// must go through the general path instead.
+__device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
+                                                 float disp0, float disp1, float state[8], float& reward, uint32_t& done) {
+    const LLConst& k = d.k;
+    if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
+        for (int b = 0; b < 3; ++b)
+            if ((f.flags >> 9) & (1u << b))
+                if (ll_any_ground_overlap(d, i, f.fat[b])) return false;
+    }
+    float m_power, s_power;
+    ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, m_power, s_power);
+
+    // ---- b2Island::Solve, island = {leg1, lander, leg0}, joints in DFS order [joint(leg1), joint(leg0)] ----
+    const float dt = 1.0f / 50.0f, inv_dt = 1.0f / dt, h = dt;
+    const float dtRatio = ((f.flags & F_STEPPED) ? inv_dt : 0.0f) * dt;
+    Pos pos[3]; Vel vel[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        Body& bd = f.b[b];
+        bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a;
+        pos[b].c = bd.sw.c; pos[b].a = bd.sw.a;
+        integrate_velocity(bd, b == 0 ? 0 : 1, k, h, vel[b].v, vel[b].w);
+    }
+    rj_init_velocity(f.jt[1], 2, k, pos, vel, dtRatio);
+    rj_init_velocity(f.jt[0], 1, k, pos, vel, dtRatio);
+    for (int it = 0; it < 180; ++it) {
+        rj_solve_velocity(f.jt[1], 1, k, vel[0].v, vel[0].w, vel[2].v, vel[2].w, dt, inv_dt);
+        rj_solve_velocity(f.jt[0], 0, k, vel[0].v, vel[0].w, vel[1].v, vel[1].w, dt, inv_dt);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) integrate_position(pos[b].c, pos[b].a, vel[b].v, vel[b].w, h);
+    bool positionSolved = false;
+    for (int it = 0; it < 60; ++it) {
+        bool ok1 = rj_solve_position(f.jt[1], 1, k, pos[0], pos[2]);
+        bool ok0 = rj_solve_position(f.jt[0], 0, k, pos[0], pos[1]);
+        if (ok1 && ok0) { positionSolved = true; break; }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        Body& bd = f.b[b];
+        bd.sw.c = pos[b].c; bd.sw.a = pos[b].a; bd.v = vel[b].v; bd.w = vel[b].w;
+        body_sync_transform(bd);
+    }
+    float minSleepTime = FLT_MAX;
+    minSleepTime = sleep_update(f.b[2], h, minSleepTime);
+    minSleepTime = sleep_update(f.b[0], h, minSleepTime);
+    minSleepTime = sleep_update(f.b[1], h, minSleepTime);
+    if (minSleepTime >= b2_timeToSleep && positionSolved)
+        for (int b = 0; b < 3; ++b) body_set_awake(f.b[b], false);
+
+    // b2Body::SynchronizeFixtures in body-list order (leg1, leg0, lander), then FindNewContacts
+    for (int b = 2; b >= 0; --b) {
+        Body& bd = f.b[b];
+        Xf xf1 = bd.xf;
+        if (bd.awake) {
+            xf1.q = rot_set(bd.sw.a0);
+            xf1.p = bd.sw.c0 - rmul(xf1.q, bd.sw.localCenter);
+        }
+        AABB a1 = poly_aabb(tab, poly_of(b), xf1), a2 = poly_aabb(tab, poly_of(b), bd.xf);
+        AABB aabb;
+        aabb.lo = mk(fmin2(a1.lo.x, a2.lo.x), fmin2(a1.lo.y, a2.lo.y));
+        aabb.hi = mk(fmax2(a1.hi.x, a2.hi.x), fmax2(a1.hi.y, a2.hi.y));
+        V2 c1 = 0.5f * (a1.lo + a1.hi), c2 = 0.5f * (a2.lo + a2.hi);
+        if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1))
+            if (ll_any_ground_overlap(d, i, f.fat[b])) return false;  // a contact would be created: general path
+    }
+    // SolveTOI: no contacts.  ClearForces; inv_dt0 = inv_dt.
+    ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, m_power, s_power, state, reward, done);
+    return true;
+}
+
+}  // namespace mgym

@@ -523,6 +523,41 @@ LLD bool rj_solve_position(const Joint& j, int ji, const LLConst& k, Pos& pA, Po
     return positionError <= b2_linearSlop && angularError <= b2_angularSlop;
 }
 
+// b2Island::Solve pieces shared by the general island solver and the contact-free fast path (ll_free.h)
+LLD void integrate_velocity(const Body& b, int t, const LLConst& k, float h, V2& v_out, float& w_out) {
+    V2 v = b.v; float wv = b.w;
+    v = v + (h * k.invMass[t]) * ((1.0f * k.mass[t]) * mk(0.0f, k.gravity) + b.force);
+    wv += h * k.invI[t] * b.torque;
+    v = (1.0f / (1.0f + h * 0.0f)) * v;
+    wv *= 1.0f / (1.0f + h * 0.0f);
+    v_out = v; w_out = wv;
+}
+LLD void integrate_position(V2& c, float& a, V2& v, float& wv, float h) {
+    V2 translation = h * v;
+    if (dot(translation, translation) > b2_maxTranslationSquared) {
+        float ratio = b2_maxTranslation / len(translation);
+        v = ratio * v;
+    }
+    float rotation = h * wv;
+    if (rotation * rotation > b2_maxRotationSquared) {
+        float ratio = b2_maxRotation / fabs1(rotation);
+        wv *= ratio;
+    }
+    c = c + h * v;
+    a += h * wv;
+}
+// sleep bookkeeping of one island body; returns the updated minSleepTime
+LLD float sleep_update(Body& b, float h, float minSleepTime) {
+    const float linTolSqr = b2_linearSleepTolerance * b2_linearSleepTolerance;
+    const float angTolSqr = b2_angularSleepTolerance * b2_angularSleepTolerance;
+    if (b.w * b.w > angTolSqr || dot(b.v, b.v) > linTolSqr) {
+        b.sleepTime = 0.0f;
+        return 0.0f;
+    }
+    b.sleepTime += h;
+    return fmin2(minSleepTime, b.sleepTime);
+}
+
 // ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
 LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, float inv_dt, float dtRatio) {
     for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
@@ -569,13 +604,9 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
     for (int i = 0; i < 3; ++i) {  // all three bodies are always in the island (joints connect them)
         Body& b = w.b[i];
         const int t = poly_of(i);
-        V2 v = b.v; float wv = b.w;
         b.sw.c0 = b.sw.c; b.sw.a0 = b.sw.a;
-        v = v + (h * k.invMass[t]) * ((1.0f * k.mass[t]) * mk(0.0f, k.gravity) + b.force);
-        wv += h * k.invI[t] * b.torque;
-        v = (1.0f / (1.0f + h * 0.0f)) * v;
-        wv *= 1.0f / (1.0f + h * 0.0f);
-        pos[i].c = b.sw.c; pos[i].a = b.sw.a; vel[i].v = v; vel[i].w = wv;
+        pos[i].c = b.sw.c; pos[i].a = b.sw.a;
+        integrate_velocity(b, t, k, h, vel[i].v, vel[i].w);
     }
 
     CSolver cs;
@@ -593,20 +624,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
     cs_store_impulses(cs, w);
 
     for (int i = 0; i < 3; ++i) {
-        V2 c = pos[i].c; float a = pos[i].a; V2 v = vel[i].v; float wv = vel[i].w;
-        V2 translation = h * v;
-        if (dot(translation, translation) > b2_maxTranslationSquared) {
-            float ratio = b2_maxTranslation / len(translation);
-            v = ratio * v;
-        }
-        float rotation = h * wv;
-        if (rotation * rotation > b2_maxRotationSquared) {
-            float ratio = b2_maxRotation / fabs1(rotation);
-            wv *= ratio;
-        }
-        c = c + h * v;
-        a += h * wv;
-        pos[i].c = c; pos[i].a = a; vel[i].v = v; vel[i].w = wv;
+        integrate_position(pos[i].c, pos[i].a, vel[i].v, vel[i].w, h);
     }
 
     bool positionSolved = false;
@@ -628,18 +646,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
     }
 
     float minSleepTime = FLT_MAX;
-    const float linTolSqr = b2_linearSleepTolerance * b2_linearSleepTolerance;
-    const float angTolSqr = b2_angularSleepTolerance * b2_angularSleepTolerance;
-    for (int q = 0; q < nb; ++q) {
-        Body& b = w.b[ibody[q]];
-        if (b.w * b.w > angTolSqr || dot(b.v, b.v) > linTolSqr) {
-            b.sleepTime = 0.0f;
-            minSleepTime = 0.0f;
-        } else {
-            b.sleepTime += h;
-            minSleepTime = fmin2(minSleepTime, b.sleepTime);
-        }
-    }
+    for (int q = 0; q < nb; ++q) minSleepTime = sleep_update(w.b[ibody[q]], h, minSleepTime);
     if (minSleepTime >= b2_timeToSleep && positionSolved)
         for (int i = 0; i < 3; ++i) body_set_awake(w.b[i], false);
 

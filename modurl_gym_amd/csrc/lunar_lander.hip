@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "ll_env.h"
+#include "ll_free.h"
 
 namespace mgym {
 
@@ -30,72 +31,137 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 }
 
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
+constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 
+struct LLIo {
+    const uint32_t* act;
+    float* obs_out;
+    float* rew;
+    uint8_t* done_out;
+    uint8_t* trunc_out;
+};
+
+__device__ __forceinline__ void ll_write_obs(const LLDev& d, const LLIo& io, uint64_t i, const float state[8]) {
+    for (int q = 0; q < 8; ++q) {
+        d.obs[(uint64_t)q * d.n_pad + i] = state[q];
+        if (io.obs_out) io.obs_out[(uint64_t)q * d.n + i] = state[q];
+    }
+}
+
+// wave-aggregated append of env indices to the worklist (done-mask style ballot + one atomic per wave)
+__device__ __forceinline__ void ll_push(const LLDev& d, bool want, uint32_t entry) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(d.work_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    if (want) d.work_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+}
+
+// Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
+// stepped here with the register-only fast path (ll_free.h); everything else — and every env the fast path
+// declines or that finished and must auto-reset — goes to the worklist for ll_general_kernel.
 __global__ void __launch_bounds__(kLLBlock)
-ll_step_kernel(LLDev d, const uint32_t* __restrict__ act, float* __restrict__ obs_out, float* __restrict__ rew,
-               uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+ll_free_kernel(LLDev d, LLIo io) {
+    __shared__ PolyTab tab;
+    stage_tab(tab, d.k);
+    bool not_reset = false;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // wave-uniform trip count
+        const uint64_t i = base + threadIdx.x;
+        const bool valid = i < d.n;
+        bool to_general = false, to_reset = false;
+        if (valid) {
+            const uint32_t flags = ST(C_FLAGS);
+            if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+                not_reset = true;
+                if (io.rew) io.rew[i] = 0.0f;
+                if (io.done_out) io.done_out[i] = 0;
+                if (io.trunc_out) io.trunc_out[i] = 0;
+            } else if (!ll_free_eligible(flags)) {
+                to_general = true;
+            } else {
+                FreeRegs f; EnvRegs e;
+                ll_free_load(d, i, f, e);
+                float state[8], reward, d0, d1; uint32_t done;
+                ll_dispersion(d, i, e, d0, d1);
+                if (ll_free_env_step(d, i, f, e, tab, io.act[i], d0, d1, state, reward, done)) {
+                    ll_free_store(d, i, f, e);
+                    if (io.rew) io.rew[i] = reward;
+                    if (io.done_out) io.done_out[i] = (uint8_t)done;
+                    if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
+                    ll_write_obs(d, io, i, state);
+                    to_reset = d.auto_reset && done;
+                } else {
+                    to_general = true;
+                }
+            }
+        }
+        ll_push(d, to_general, (uint32_t)i);
+        ll_push(d, to_reset, (uint32_t)i | kWorkReset);
+    }
+    if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
+}
+
+// General path on a compacted population.  list != nullptr: entries of the worklist (general steps and resets);
+// list == nullptr: every env with `forced` = 0 general step, 1 reset(), 2 Testable::reset_deterministic.
+__global__ void __launch_bounds__(kLLBlock)
+ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int forced) {
     __shared__ PolyTab tab;
     stage_tab(tab, d.k);
     bool not_reset = false, overflow = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t total = list ? (uint64_t)*count : d.n;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t i = q;
+        int mode = forced;
+        if (list) { uint32_t ent = list[q]; i = ent & ~kWorkReset; mode = (ent & kWorkReset) ? 1 : 0; }
         World w; EnvRegs e;
         ll_load(d, i, w, e);
-        if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
-            not_reset = true;
-            if (rew) rew[i] = 0.0f;
-            if (done_out) done_out[i] = 0;
-            if (trunc_out) trunc_out[i] = 0;
-            continue;
+        float state[8];
+        if (mode == 0) {
+            if (!e.has_world) {
+                not_reset = true;
+                if (io.rew) io.rew[i] = 0.0f;
+                if (io.done_out) io.done_out[i] = 0;
+                if (io.trunc_out) io.trunc_out[i] = 0;
+                continue;
+            }
+            float reward, d0, d1; uint32_t done;
+            ll_dispersion(d, i, e, d0, d1);
+            ll_env_step(w, e, tab, d.k, io.act[i], d0, d1, state, reward, done);
+            if (io.rew) io.rew[i] = reward;
+            if (io.done_out) io.done_out[i] = (uint8_t)done;
+            if (io.trunc_out) io.trunc_out[i] = 0;
+            if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, state);
+        } else if (mode == 1) {
+            ll_env_reset(d, i, w, e, tab, state);
+        } else {
+            const float H = VIEWPORT_H / SCALE;
+            float height[12];
+            for (int t = 0; t < 12; ++t) height[t] = H / 8.0f;  // :1278-1280
+            ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
+            e.step = 1u;
+            ll_observe(w.b[0], w.legs[0], w.legs[1], state);  // :1441
         }
-        float state[8], reward, d0, d1; uint32_t done;
-        ll_dispersion(d, i, e, d0, d1);
-        ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
-        if (rew) rew[i] = reward;
-        if (done_out) done_out[i] = (uint8_t)done;
-        if (trunc_out) trunc_out[i] = 0;  // :1165 truncated: false
-        if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, state);
         overflow |= w.overflow;
         ll_store(d, i, w, e);
-        for (int q = 0; q < 8; ++q) {
-            d.obs[(uint64_t)q * d.n_pad + i] = state[q];
-            if (obs_out) obs_out[(uint64_t)q * d.n + i] = state[q];
-        }
+        ll_write_obs(d, io, i, state);
     }
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
     if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
 }
 
-// mode 0: reset() for masked envs; mode 1: Testable::reset_deterministic (lunar_lander.rs:1249-1442) for all
-__global__ void __launch_bounds__(kLLBlock)
-ll_reset_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int all, int mode, float* __restrict__ obs_out) {
-    __shared__ PolyTab tab;
-    stage_tab(tab, d.k);
-    bool overflow = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (uint64_t)gridDim.x * blockDim.x) {
-        bool m = all;
-        if (!all) m = (m0 && m0[i]) || (m1 && m1[i]);
-        if (!m) continue;
-        World w; EnvRegs e;
-        ll_load(d, i, w, e);
-        float state[8];
-        if (mode == 0) {
-            ll_env_reset(d, i, w, e, tab, state);
-        } else {
-            const float H = VIEWPORT_H / SCALE;
-            float height[12];
-            for (int q = 0; q < 12; ++q) height[q] = H / 8.0f;  // :1278-1280
-            ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
-            e.step = 1u;
-            ll_observe(w, state);  // :1441
-        }
-        overflow |= w.overflow;
-        ll_store(d, i, w, e);
-        for (int q = 0; q < 8; ++q) {
-            d.obs[(uint64_t)q * d.n_pad + i] = state[q];
-            if (obs_out) obs_out[(uint64_t)q * d.n + i] = state[q];
-        }
+// masked reset: scan the masks (1-2 B/env) and compact the masked envs into the worklist
+__global__ void __launch_bounds__(256)
+ll_mask_scan_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {
+        const uint64_t i = base + threadIdx.x;
+        bool m = false;
+        if (i < d.n) m = (m0 && m0[i]) || (m1 && m1[i]);
+        ll_push(d, m, (uint32_t)i | kWorkReset);
     }
-    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
 }
 
 // state blob (27 columns, identical to the CPU oracle's): raw {x,y,angle,vx,vy,w} of lander, leg0, leg1;
@@ -142,11 +208,13 @@ __global__ void __launch_bounds__(kLLBlock) ll_import_kernel(LLDev d, const uint
 struct LunarLanderEnv final : Env {
     void* base = nullptr;
     void* obs_base = nullptr;
+    void* work_base = nullptr;
     LLDev dev{};
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
         if (obs_base) (void)hipFree(obs_base);
+        if (work_base) (void)hipFree(work_base);
     }
 
     int init() override {
@@ -158,6 +226,10 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemsetAsync(obs_base, 0, (size_t)8 * n_pad * sizeof(float), stream));
         dev.st = static_cast<uint32_t*>(base);
         dev.obs = static_cast<float*>(obs_base);
+        MGYM_HIP(hipMalloc(&work_base, (size_t)(n_pad + 64) * sizeof(uint32_t)));
+        MGYM_HIP(hipMemsetAsync(work_base, 0, (size_t)(n_pad + 64) * sizeof(uint32_t), stream));
+        dev.work_count = static_cast<uint32_t*>(work_base);
+        dev.work_list = static_cast<uint32_t*>(work_base) + 64;
         dev.disp = nullptr;
         dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
@@ -170,22 +242,38 @@ struct LunarLanderEnv final : Env {
         if (b > 65536) b = 65536;
         return dim3((unsigned)(b ? b : 1));
     }
+    dim3 work_grid() const {  // the worklist length is only known on the device: fixed grid, grid-stride inside
+        uint64_t b = (n + kLLBlock - 1) / kLLBlock;
+        if (b > 4096) b = 4096;
+        return dim3((unsigned)(b ? b : 1));
+    }
 
     int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) override {
         if (n == 0) return MGYM_OK;
-        hipLaunchKernelGGL(ll_reset_kernel, grid(), dim3(kLLBlock), 0, stream, dev, m0, m1, all ? 1 : 0, 0, obs_out);
+        LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
+        if (all) {
+            hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
+        } else {
+            MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
+            hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+        }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
     int reset_deterministic(float* obs_out) override {
         if (n == 0) return MGYM_OK;
-        hipLaunchKernelGGL(ll_reset_kernel, grid(), dim3(kLLBlock), 0, stream, dev, (const uint8_t*)nullptr, (const uint8_t*)nullptr, 1, 1, obs_out);
+        LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 2);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
-        hipLaunchKernelGGL(ll_step_kernel, grid(), dim3(kLLBlock), 0, stream, dev, static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc);
+        LLIo io{static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc};
+        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(ll_free_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io);
+        hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

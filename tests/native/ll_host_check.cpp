@@ -10,7 +10,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#include "../../modurl_gym_amd/csrc/ll_env.h"
+#include "../../modurl_gym_amd/csrc/ll_free.h"
 extern "C" {
 #include "../../oracle/oracle.h"
 }
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
     std::vector<uint32_t> act(n);
     if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
+    unsigned long fast_steps = 0, general_steps = 0;
     int max_slots = 0; unsigned long hist[kSlots + 1] = {0};
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -51,7 +52,7 @@ int main(int argc, char** argv) {
         if (deterministic) {
             float height[12]; for (int q = 0; q < 12; ++q) height[q] = (400.0f / 30.0f) / 8.0f;
             ll_build_scene(w, e, tab, d.k, height, 400.0f / 30.0f * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
-            e.step = 1u; ll_observe(w, state);
+            e.step = 1u; ll_observe(w.b[0], w.legs[0], w.legs[1], state);
         } else ll_env_reset(d, i, w, e, tab, state);
         ll_store(d, i, w, e);
         for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; if (!closef(state[q], oobs[q * n + i])) { if (mism < 10) printf("reset env %lu obs[%d] %.9g vs %.9g\n", (unsigned long)i, q, state[q], oobs[q * n + i]); mism++; } }
@@ -61,13 +62,25 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < n; ++i) { rs = rs * 1664525u + 1013904223u; act[i] = (rs >> 16) & 3u; }
         ora_vec_step(ov, act.data(), oobs.data(), orew.data(), odone.data(), otr.data(), 1);
         for (uint64_t i = 0; i < n; ++i) {
-            World w; EnvRegs e; float state[8], reward, d0, d1; uint32_t done;
-            ll_load(d, i, w, e);
-            ll_dispersion(d, i, e, d0, d1);
-            ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
-            if (w.overflow) overflow++;
-            { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
-            ll_store(d, i, w, e);
+            float state[8], reward, d0, d1; uint32_t done;
+            // same dispatch as ll_free_kernel / ll_general_kernel: fast path when eligible and it accepts
+            bool fast = false;
+            if (ll_free_eligible(d.st[(uint64_t)C_FLAGS * d.n_pad + i])) {
+                FreeRegs f; EnvRegs e;
+                ll_free_load(d, i, f, e);
+                ll_dispersion(d, i, e, d0, d1);
+                if (ll_free_env_step(d, i, f, e, tab, act[i], d0, d1, state, reward, done)) { ll_free_store(d, i, f, e); fast = true; fast_steps++; }
+            }
+            if (!fast) {
+                World w; EnvRegs e;
+                ll_load(d, i, w, e);
+                ll_dispersion(d, i, e, d0, d1);
+                ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
+                if (w.overflow) overflow++;
+                { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
+                ll_store(d, i, w, e);
+                general_steps++;
+            }
             bool bad = done != odone[i] || !closef(reward, orew[i]);
             for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; bad |= !closef(state[q], oobs[q * n + i]); }
             if (bad) {
@@ -85,6 +98,7 @@ int main(int argc, char** argv) {
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
+    printf("fast-path steps %lu, general-path steps %lu\n", fast_steps, general_steps);
     printf("max simultaneous cached contacts %d; histogram:", max_slots);
     for (int q = 0; q <= kSlots; ++q) printf(" %lu", hist[q]);
     printf("\n");
