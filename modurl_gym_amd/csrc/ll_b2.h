@@ -326,6 +326,7 @@ struct VConstraint {
     int indexB;       // dynamic body 0..2
     float invMassB, invIB, friction;
     int pointCount, slot;
+    int pad_;     // 31 words: odd record stride => conflict-free per-lane columns in LDS
 };
 struct PConstraint {
     V2 localPoints[2], localNormal, localPoint, localCenterB;

@@ -271,11 +271,11 @@ __device__ __forceinline__ void ll_post_step(const Body& lander, bool game_over,
 }
 
 // step(), lunar_lander.rs:919-1167.  disp = the two raw U(-1,1) draws of :973-974.
-__device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, uint32_t action, float disp0, float disp1,
-                            float state[8], float& reward, uint32_t& done) {
+__device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
+                            float disp1, float state[8], float& reward, uint32_t& done) {
     float m_power, s_power;
     ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, k, action, disp0, disp1, m_power, s_power);
-    world_step(w, tab, k);  // :1066
+    world_step(w, tab, k, mem);  // :1066
     ll_post_step(w.b[0], w.game_over, w.legs[0], w.legs[1], e, m_power, s_power, state, reward, done);
 }
 
@@ -333,7 +333,7 @@ __device__ __forceinline__ void ll_dispersion(const LLDev& d, uint64_t i, const 
 }
 
 // reset(), lunar_lander.rs:727-917 (episode counter = Philox counter word 2)
-__device__ void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, const PolyTab& tab, float state[8]) {
+__device__ void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, const PolyTab& tab, const CSolverMem& mem, float state[8]) {
     const uint64_t gid = d.env_id_base + i;
     uint32_t r[16];
     for (uint32_t s = 0; s < 4; ++s) {
@@ -349,7 +349,7 @@ __device__ void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, c
     e.step = 0u;
     float d0, d1, reward; uint32_t done;
     ll_dispersion(d, i, e, d0, d1);
-    ll_env_step(w, e, tab, d.k, 0u, d0, d1, state, reward, done);  // :911-916
+    ll_env_step(w, e, tab, d.k, mem, 0u, d0, d1, state, reward, done);  // :911-916
     e.episode += 1u;
 }
 

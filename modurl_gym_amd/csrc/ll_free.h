@@ -150,8 +150,8 @@ __device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, Fre
         pos[b].c = bd.sw.c; pos[b].a = bd.sw.a;
         integrate_velocity(bd, b == 0 ? 0 : 1, k, h, vel[b].v, vel[b].w);
     }
-    rj_init_velocity(f.jt[1], 2, k, pos, vel, dtRatio);
-    rj_init_velocity(f.jt[0], 1, k, pos, vel, dtRatio);
+    rj_init_velocity(f.jt[1], 2, k, pos[0].a, pos[2].a, vel[0], vel[2], dtRatio);
+    rj_init_velocity(f.jt[0], 1, k, pos[0].a, pos[1].a, vel[0], vel[1], dtRatio);
     for (int it = 0; it < 180; ++it) {
         rj_solve_velocity(f.jt[1], 1, k, vel[0].v, vel[0].w, vel[2].v, vel[2].w, dt, inv_dt);
         rj_solve_velocity(f.jt[0], 0, k, vel[0].v, vel[0].w, vel[1].v, vel[1].w, dt, inv_dt);

@@ -200,25 +200,35 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
 }
 
 // ---- contact solver over a list of slots --------------------------------------------------------------
+// Constraint storage is supplied by the caller: on the GPU the velocity constraints live in LDS, one
+// column per lane (element i of lane l at vc[i * stride], stride = 64), the position constraints in local
+// memory; the host test passes plain arrays with stride 1.
+struct CSolverMem { VConstraint* vc; int vc_stride; PConstraint* pc; int pc_stride; int cap; };
 struct CSolver {
-    VConstraint vc[kSlots];
-    PConstraint pc[kSlots];
+    VConstraint* vc; int vs;
+    PConstraint* pc; int ps;
     int count;
 };
+// body-indexed access to three register-resident velocity / position records
+struct Vel3 { Vel b[3]; };
+LLD Vel vel_get(const Vel3& v, int i) { return v.b[i]; }
+LLD void vel_set(Vel3& v, int i, Vel x) { v.b[i] = x; }
 
-LLD void cs_init(CSolver& s, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
+LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
+    s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
+    if (count > mem.cap) { w.overflow = true; count = mem.cap; }
     s.count = count;
     for (int i = 0; i < count; ++i) {
         Contact& contact = w.ct[slots[i]];
         const Manifold& manifold = contact.m;
         const int t = poly_of(contact.body);
-        VConstraint& vc = s.vc[i];
+        VConstraint& vc = s.vc[i * s.vs];
         vc.friction = k.friction[t];
         vc.indexB = contact.body;
         vc.invMassB = k.invMass[t]; vc.invIB = k.invI[t];
         vc.slot = slots[i]; vc.pointCount = manifold.pointCount;
         vc.k11 = vc.k12 = vc.k21 = vc.k22 = 0.0f; vc.nm11 = vc.nm12 = vc.nm21 = vc.nm22 = 0.0f;
-        PConstraint& pc = s.pc[i];
+        PConstraint& pc = s.pc[i * s.ps];
         pc.indexB = contact.body; pc.invMassB = k.invMass[t]; pc.invIB = k.invI[t];
         pc.localCenterB = k.localCenter[t];
         pc.localNormal = manifold.localNormal; pc.localPoint = manifold.localPoint;
@@ -241,14 +251,15 @@ LLD void cs_init(CSolver& s, World& w, const LLConst& k, const int* slots, int c
 
 // b2ContactSolver::InitializeVelocityConstraints.  restitution = 0: velocityBias = -0 * vRel (a signed
 // zero when vRel < -threshold), which only ever enters `vn - velocityBias` and is therefore left at 0.
-LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel* vel) {
+LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel3& vel) {
     for (int i = 0; i < s.count; ++i) {
-        VConstraint& vc = s.vc[i];
-        const PConstraint& pc = s.pc[i];
+        VConstraint& vc = s.vc[i * s.vs];
+        const PConstraint& pc = s.pc[i * s.ps];
         const Manifold& manifold = w.ct[vc.slot].m;
         const float mB = vc.invMassB, iB = vc.invIB;
         V2 cB = pos[vc.indexB].c; float aB = pos[vc.indexB].a;
-        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        const Vel velB = vel_get(vel, vc.indexB);
+        V2 vB = velB.v; float wB = velB.w;
         Xf xfB;
         xfB.q = rot_set(aB);
         xfB.p = cB - rmul(xfB.q, pc.localCenterB);
@@ -289,11 +300,12 @@ LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel*
     }
 }
 
-LLD void cs_warm_start(const CSolver& s, Vel* vel) {  // b2ContactSolver::WarmStart
+LLD void cs_warm_start(const CSolver& s, Vel3& vel) {  // b2ContactSolver::WarmStart
     for (int i = 0; i < s.count; ++i) {
-        const VConstraint& vc = s.vc[i];
+        const VConstraint& vc = s.vc[i * s.vs];
         const float mB = vc.invMassB, iB = vc.invIB;
-        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        const Vel velB = vel_get(vel, vc.indexB);
+        V2 vB = velB.v; float wB = velB.w;
         V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
         for (int j = 0; j < vc.pointCount; ++j) {
             const VCPoint& vcp = vc.points[j];
@@ -301,7 +313,8 @@ LLD void cs_warm_start(const CSolver& s, Vel* vel) {  // b2ContactSolver::WarmSt
             wB += iB * cross(vcp.rB, P);
             vB = vB + mB * P;
         }
-        vel[vc.indexB].v = vB; vel[vc.indexB].w = wB;
+        Vel outB; outB.v = vB; outB.w = wB;
+        vel_set(vel, vc.indexB, outB);
     }
 }
 
@@ -313,12 +326,13 @@ LLD void cs_apply2(const VConstraint& vc, V2 x, V2 a, V2 normal, V2& vB, float& 
     cp1.normalImpulse = x.x; cp2.normalImpulse = x.y;
 }
 
-LLD void cs_solve_velocity(CSolver& s, Vel* vel) {  // b2ContactSolver::SolveVelocityConstraints
+LLD void cs_solve_velocity(CSolver& s, Vel3& vel) {  // b2ContactSolver::SolveVelocityConstraints
     for (int i = 0; i < s.count; ++i) {
-        VConstraint& vc = s.vc[i];
+        VConstraint& vc = s.vc[i * s.vs];
         const float mB = vc.invMassB, iB = vc.invIB;
         const int pointCount = vc.pointCount;
-        V2 vB = vel[vc.indexB].v; float wB = vel[vc.indexB].w;
+        const Vel velB = vel_get(vel, vc.indexB);
+        V2 vB = velB.v; float wB = velB.w;
         V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
         const float friction = vc.friction;
         for (int j = 0; j < pointCount; ++j) {
@@ -369,13 +383,14 @@ LLD void cs_solve_velocity(CSolver& s, Vel* vel) {  // b2ContactSolver::SolveVel
                 break;
             }
         }
-        vel[vc.indexB].v = vB; vel[vc.indexB].w = wB;
+        Vel outB; outB.v = vB; outB.w = wB;
+        vel_set(vel, vc.indexB, outB);
     }
 }
 
 LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::StoreImpulses
     for (int i = 0; i < s.count; ++i) {
-        const VConstraint& vc = s.vc[i];
+        const VConstraint& vc = s.vc[i * s.vs];
         Manifold& manifold = w.ct[vc.slot].m;
         for (int j = 0; j < vc.pointCount; ++j) {
             manifold.points[j].normalImpulse = vc.points[j].normalImpulse;
@@ -389,7 +404,7 @@ LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::St
 LLD bool cs_solve_position(const CSolver& s, Pos* pos, bool toi) {
     float minSeparation = 0.0f;
     for (int i = 0; i < s.count; ++i) {
-        const PConstraint& pc = s.pc[i];
+        const PConstraint& pc = s.pc[i * s.ps];
         const float mB = pc.invMassB, iB = pc.invIB;
         V2 cB = pos[pc.indexB].c; float aB = pos[pc.indexB].a;
         for (int j = 0; j < pc.pointCount; ++j) {
@@ -414,10 +429,10 @@ LLD bool cs_solve_position(const CSolver& s, Pos* pos, bool toi) {
 }
 
 // ---- revolute joint ---------------------------------------------------------------------------------------
-LLD void rj_init_velocity(Joint& j, int leg, const LLConst& k, const Pos* pos, Vel* vel, float dtRatio) {
+LLD void rj_init_velocity(Joint& j, int leg, const LLConst& k, float aA, float aB, Vel& velA, Vel& velB, float dtRatio) {
     const int ji = leg - 1;
-    float aA = pos[0].a; V2 vA = vel[0].v; float wA = vel[0].w;
-    float aB = pos[leg].a; V2 vB = vel[leg].v; float wB = vel[leg].w;
+    V2 vA = velA.v; float wA = velA.w;
+    V2 vB = velB.v; float wB = velB.w;
     Rot qA = rot_set(aA), qB = rot_set(aB);
     j.rA = rmul(qA, mk(0.0f, 0.0f) - k.localCenter[0]);
     j.rB = rmul(qB, k.localAnchorB[ji] - k.localCenter[1]);
@@ -437,7 +452,7 @@ LLD void rj_init_velocity(Joint& j, int leg, const LLConst& k, const Pos* pos, V
     wA -= iA * (cross(j.rA, P) + axialImpulse);
     vB = vB + mB * P;
     wB += iB * (cross(j.rB, P) + axialImpulse);
-    vel[0].v = vA; vel[0].w = wA; vel[leg].v = vB; vel[leg].w = wB;
+    velA.v = vA; velA.w = wA; velB.v = vB; velB.w = wB;
 }
 
 LLD void rj_solve_velocity(Joint& j, int ji, const LLConst& k, V2& vA, float& wA, V2& vB, float& wB, float dt, float inv_dt) {
@@ -559,7 +574,7 @@ LLD float sleep_update(Body& b, float h, float minSleepTime) {
 }
 
 // ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
-LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, float inv_dt, float dtRatio) {
+LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, float inv_dt, float dtRatio) {
     for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
     for (int s = 0; s < kSlots; ++s) w.ct[s].islandFlag = false;
     int seed = -1;
@@ -599,33 +614,48 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
         }
     }
 
-    Pos pos[3]; Vel vel[3];
+    Pos pos[3]; Vel3 vel;
     const float h = dt;
     for (int i = 0; i < 3; ++i) {  // all three bodies are always in the island (joints connect them)
         Body& b = w.b[i];
         const int t = poly_of(i);
         b.sw.c0 = b.sw.c; b.sw.a0 = b.sw.a;
         pos[i].c = b.sw.c; pos[i].a = b.sw.a;
-        integrate_velocity(b, t, k, h, vel[i].v, vel[i].w);
+        Vel vi;
+        integrate_velocity(b, t, k, h, vi.v, vi.w);
+        vel_set(vel, i, vi);
     }
 
     CSolver cs;
-    cs_init(cs, w, k, icontact, nc, true, dtRatio);
+    cs_init(cs, mem, w, k, icontact, nc, true, dtRatio);
     cs_init_velocity(cs, w, pos, vel);
     cs_warm_start(cs, vel);
-    for (int i = 0; i < nj; ++i) rj_init_velocity(w.jt[ijoint[i]], 1 + ijoint[i], k, pos, vel, dtRatio);
+    // both joints are always in the island; DFS order is [joint(leg1), joint(leg0)] unless the seed was leg0
+    const bool leg1_first = ijoint[0] == 1;
+    Joint J0 = w.jt[0], J1 = w.jt[1];  // register copies for the 180 sweeps
+    if (leg1_first) {
+        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b[0], vel.b[2], dtRatio);
+        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b[0], vel.b[1], dtRatio);
+    } else {
+        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b[0], vel.b[1], dtRatio);
+        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b[0], vel.b[2], dtRatio);
+    }
     for (int it = 0; it < 180; ++it) {
-        for (int i = 0; i < nj; ++i) {
-            const int jj = ijoint[i];
-            rj_solve_velocity(w.jt[jj], jj, k, vel[0].v, vel[0].w, vel[1 + jj].v, vel[1 + jj].w, dt, inv_dt);
+        if (leg1_first) {
+            rj_solve_velocity(J1, 1, k, vel.b[0].v, vel.b[0].w, vel.b[2].v, vel.b[2].w, dt, inv_dt);
+            rj_solve_velocity(J0, 0, k, vel.b[0].v, vel.b[0].w, vel.b[1].v, vel.b[1].w, dt, inv_dt);
+        } else {
+            rj_solve_velocity(J0, 0, k, vel.b[0].v, vel.b[0].w, vel.b[1].v, vel.b[1].w, dt, inv_dt);
+            rj_solve_velocity(J1, 1, k, vel.b[0].v, vel.b[0].w, vel.b[2].v, vel.b[2].w, dt, inv_dt);
         }
         cs_solve_velocity(cs, vel);
     }
+    w.jt[0] = J0; w.jt[1] = J1;
     cs_store_impulses(cs, w);
 
-    for (int i = 0; i < 3; ++i) {
-        integrate_position(pos[i].c, pos[i].a, vel[i].v, vel[i].w, h);
-    }
+    integrate_position(pos[0].c, pos[0].a, vel.b[0].v, vel.b[0].w, h);
+    integrate_position(pos[1].c, pos[1].a, vel.b[1].v, vel.b[1].w, h);
+    integrate_position(pos[2].c, pos[2].a, vel.b[2].v, vel.b[2].w, h);
 
     bool positionSolved = false;
     for (int it = 0; it < 60; ++it) {
@@ -641,7 +671,8 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
 
     for (int i = 0; i < 3; ++i) {
         Body& b = w.b[i];
-        b.sw.c = pos[i].c; b.sw.a = pos[i].a; b.v = vel[i].v; b.w = vel[i].w;
+        const Vel vi = vel_get(vel, i);
+        b.sw.c = pos[i].c; b.sw.a = pos[i].a; b.v = vi.v; b.w = vi.w;
         body_sync_transform(b);
     }
 
@@ -657,7 +688,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, float dt, 
 }
 
 // ---- b2World::SolveTOI ----------------------------------------------------------------------------------
-LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, float dt) {
+LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt) {
     for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
     bool any = false;
     for (int s = 0; s < kSlots; ++s) {
@@ -733,10 +764,11 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, float dt) {
 
         // b2Island::SolveTOI: positions/velocities of the one dynamic body (slot `dyn` of a 3-entry table)
         const float sub_dt = (1.0f - minAlpha) * dt;
-        Pos pos[3]; Vel vel[3];
-        pos[dyn].c = bB.sw.c; pos[dyn].a = bB.sw.a; vel[dyn].v = bB.v; vel[dyn].w = bB.w;
+        Pos pos[3]; Vel3 vel;
+        pos[dyn].c = bB.sw.c; pos[dyn].a = bB.sw.a;
+        { Vel vd; vd.v = bB.v; vd.w = bB.w; vel.b[0] = vd; vel.b[1] = vd; vel.b[2] = vd; }  // only slot `dyn` is referenced
         CSolver cs;
-        cs_init(cs, w, k, islandSlots, nc, false, 1.0f);
+        cs_init(cs, mem, w, k, islandSlots, nc, false, 1.0f);
         for (int i = 0; i < 20; ++i)
             if (cs_solve_position(cs, pos, true)) break;
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
@@ -744,20 +776,10 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, float dt) {
         for (int i = 0; i < 180; ++i) cs_solve_velocity(cs, vel);
         {
             const float h = sub_dt;
-            V2 c = pos[dyn].c; float a = pos[dyn].a; V2 v = vel[dyn].v; float wv = vel[dyn].w;
-            V2 translation = h * v;
-            if (dot(translation, translation) > b2_maxTranslationSquared) {
-                float ratio = b2_maxTranslation / len(translation);
-                v = ratio * v;
-            }
-            float rotation = h * wv;
-            if (rotation * rotation > b2_maxRotationSquared) {
-                float ratio = b2_maxRotation / fabs1(rotation);
-                wv *= ratio;
-            }
-            c = c + h * v;
-            a += h * wv;
-            bB.sw.c = c; bB.sw.a = a; bB.v = v; bB.w = wv;
+            Vel vd = vel_get(vel, dyn);
+            V2 c = pos[dyn].c; float a = pos[dyn].a;
+            integrate_position(c, a, vd.v, vd.w, h);
+            bB.sw.c = c; bB.sw.a = a; bB.v = vd.v; bB.w = vd.w;
             body_sync_transform(bB);
         }
         int moved[1], nm = 0;
@@ -769,7 +791,7 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, float dt) {
 }
 
 // b2World::Step(1/50, 180, 60)
-LLD void world_step(World& w, const PolyTab& tab, const LLConst& k) {
+LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem) {
     if (w.newContacts) {
         int order[3], n = 0;
         for (int i = 0; i < 3; ++i)
@@ -782,8 +804,8 @@ LLD void world_step(World& w, const PolyTab& tab, const LLConst& k) {
     const float inv_dt = 1.0f / dt;
     const float dtRatio = (w.stepped_once ? inv_dt : 0.0f) * dt;
     collide(w, tab);
-    solve_island(w, tab, k, dt, inv_dt, dtRatio);
-    solve_toi(w, tab, k, dt);
+    solve_island(w, tab, k, mem, dt, inv_dt, dtRatio);
+    solve_toi(w, tab, k, mem, dt);
     w.stepped_once = true;
     for (int i = 0; i < 3; ++i) { w.b[i].force = mk(0.0f, 0.0f); w.b[i].torque = 0.0f; }
 }

@@ -11,6 +11,7 @@
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -31,6 +32,7 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 }
 
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
+constexpr int kSolverCap = 8;            // touching contacts one island may hold (LDS: 8 x 64 lanes x 124 B = 62 KB)
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 
 struct LLIo {
@@ -109,7 +111,12 @@ ll_free_kernel(LLDev d, LLIo io) {
 __global__ void __launch_bounds__(kLLBlock)
 ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int forced) {
     __shared__ PolyTab tab;
+    // velocity constraints of the contact solver: LDS, one column per lane (31-word records: conflict-free)
+    __shared__ VConstraint s_vc[kSolverCap * kLLBlock];
     stage_tab(tab, d.k);
+    PConstraint l_pc[kSolverCap];
+    CSolverMem mem;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = kLLBlock; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     bool not_reset = false, overflow = false;
     const uint64_t total = list ? (uint64_t)*count : d.n;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
@@ -129,13 +136,13 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
             }
             float reward, d0, d1; uint32_t done;
             ll_dispersion(d, i, e, d0, d1);
-            ll_env_step(w, e, tab, d.k, io.act[i], d0, d1, state, reward, done);
+            ll_env_step(w, e, tab, d.k, mem, io.act[i], d0, d1, state, reward, done);
             if (io.rew) io.rew[i] = reward;
             if (io.done_out) io.done_out[i] = (uint8_t)done;
             if (io.trunc_out) io.trunc_out[i] = 0;
-            if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, state);
+            if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, mem, state);
         } else if (mode == 1) {
-            ll_env_reset(d, i, w, e, tab, state);
+            ll_env_reset(d, i, w, e, tab, mem, state);
         } else {
             const float H = VIEWPORT_H / SCALE;
             float height[12];
@@ -210,6 +217,7 @@ struct LunarLanderEnv final : Env {
     void* obs_base = nullptr;
     void* work_base = nullptr;
     LLDev dev{};
+    bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
@@ -271,6 +279,11 @@ struct LunarLanderEnv final : Env {
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
         LLIo io{static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc};
+        if (general_only) {  // debugging aid (MGYM_LL_GENERAL_ONLY=1): every env through the general kernel
+            hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0);
+            MGYM_HIP(hipGetLastError());
+            return MGYM_OK;
+        }
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(ll_free_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io);
         hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);

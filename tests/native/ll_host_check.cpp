@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
     std::vector<uint32_t> act(n);
     if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
+    VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
+    CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
     unsigned long fast_steps = 0, general_steps = 0;
     int max_slots = 0; unsigned long hist[kSlots + 1] = {0};
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
@@ -53,10 +55,12 @@ int main(int argc, char** argv) {
             float height[12]; for (int q = 0; q < 12; ++q) height[q] = (400.0f / 30.0f) / 8.0f;
             ll_build_scene(w, e, tab, d.k, height, 400.0f / 30.0f * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
             e.step = 1u; ll_observe(w.b[0], w.legs[0], w.legs[1], state);
-        } else ll_env_reset(d, i, w, e, tab, state);
+        } else ll_env_reset(d, i, w, e, tab, mem0, state);
         ll_store(d, i, w, e);
         for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; if (!closef(state[q], oobs[q * n + i])) { if (mism < 10) printf("reset env %lu obs[%d] %.9g vs %.9g\n", (unsigned long)i, q, state[q], oobs[q * n + i]); mism++; } }
     }
+    VConstraint h_vc[kSlots]; PConstraint h_pc[kSlots];
+    CSolverMem mem; mem.vc = h_vc; mem.vc_stride = 1; mem.pc = h_pc; mem.pc_stride = 1; mem.cap = kSlots;
     uint32_t rs = 12345;
     for (int t = 0; t < steps; ++t) {
         for (uint64_t i = 0; i < n; ++i) { rs = rs * 1664525u + 1013904223u; act[i] = (rs >> 16) & 3u; }
@@ -75,7 +79,7 @@ int main(int argc, char** argv) {
                 World w; EnvRegs e;
                 ll_load(d, i, w, e);
                 ll_dispersion(d, i, e, d0, d1);
-                ll_env_step(w, e, tab, d.k, act[i], d0, d1, state, reward, done);
+                ll_env_step(w, e, tab, d.k, mem, act[i], d0, d1, state, reward, done);
                 if (w.overflow) overflow++;
                 { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
                 ll_store(d, i, w, e);
@@ -94,7 +98,7 @@ int main(int argc, char** argv) {
         }
         if (t % 2 == 0 && !deterministic) {  // masked reset of finished envs on both sides
             ora_vec_reset(ov, mask.data(), NULL, 1);
-            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e); ll_env_reset(d, i, w, e, tab, state); ll_store(d, i, w, e); }
+            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e); ll_env_reset(d, i, w, e, tab, mem, state); ll_store(d, i, w, e); }
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
