@@ -62,7 +62,7 @@ struct EnvRegs {  // LunarLanderV3 fields beside the world (lunar_lander.rs:232-
 
 #define ST(col) d.st[(uint64_t)(col) * d.n_pad + i]
 
-__device__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e) {
+__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e) {
     const uint32_t flags = ST(C_FLAGS);
     for (int b = 0; b < 3; ++b) {
         Body& bd = w.b[b];
@@ -127,7 +127,7 @@ __device__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e) {
     e.deterministic = flags & F_DETERMINISTIC;
 }
 
-__device__ void ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e) {
+__device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e) {
     uint32_t flags = 0, ncont = 0;
     for (int b = 0; b < 3; ++b) {
         const Body& bd = w.b[b];
@@ -271,7 +271,7 @@ __device__ __forceinline__ void ll_post_step(const Body& lander, bool game_over,
 }
 
 // step(), lunar_lander.rs:919-1167.  disp = the two raw U(-1,1) draws of :973-974.
-__device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
+__device__ __forceinline__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
                             float disp1, float state[8], float& reward, uint32_t& done) {
     float m_power, s_power;
     ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, k, action, disp0, disp1, m_power, s_power);
@@ -280,7 +280,7 @@ __device__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLCo
 }
 
 // world/terrain/lander/legs construction shared by reset() (:733-908) and reset_deterministic() (:1256-1438)
-__device__ void ll_build_scene(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const float height_in[12], float initial_y,
+__device__ __forceinline__ void ll_build_scene(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const float height_in[12], float initial_y,
                                bool random_force, float u_force0, float u_force1, int32_t wind_idx, int32_t torque_idx, bool deterministic) {
     const float W = VIEWPORT_W / SCALE, H = VIEWPORT_H / SCALE;
     float height[12];
@@ -332,8 +332,8 @@ __device__ __forceinline__ void ll_dispersion(const LLDev& d, uint64_t i, const 
     d1 = u23(r.w[1]) * 2.0f + -1.0f;
 }
 
-// reset(), lunar_lander.rs:727-917 (episode counter = Philox counter word 2)
-__device__ void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, const PolyTab& tab, const CSolverMem& mem, float state[8]) {
+// reset() up to (not including) its implicit step(0): lunar_lander.rs:727-908
+__device__ __forceinline__ void ll_reset_scene(const LLDev& d, uint64_t i, World& w, EnvRegs& e, const PolyTab& tab) {
     const uint64_t gid = d.env_id_base + i;
     uint32_t r[16];
     for (uint32_t s = 0; s < 4; ++s) {
@@ -347,6 +347,11 @@ __device__ void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, c
     int32_t ti = -9999 + (int32_t)(((uint64_t)r[15] * 19998u) >> 32);
     ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE, true, u23(r[12]), u23(r[13]), wi, ti, false);
     e.step = 0u;
+}
+
+// reset(), lunar_lander.rs:727-917 (episode counter = Philox counter word 2)
+__device__ inline void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvRegs& e, const PolyTab& tab, const CSolverMem& mem, float state[8]) {
+    ll_reset_scene(d, i, w, e, tab);
     float d0, d1, reward; uint32_t done;
     ll_dispersion(d, i, e, d0, d1);
     ll_env_step(w, e, tab, d.k, mem, 0u, d0, d1, state, reward, done);  // :911-916

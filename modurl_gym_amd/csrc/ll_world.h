@@ -5,6 +5,10 @@
 #pragma once
 #include "ll_b2.h"
 
+#ifndef LL_STAMP
+#define LL_STAMP(id)  // diagnostic builds (tools/ll_phase_prof.hip) define this to stamp wave cycles per phase
+#endif
+
 namespace mgym {
 namespace ll {
 
@@ -210,9 +214,15 @@ struct CSolver {
     int count;
 };
 // body-indexed access to three register-resident velocity / position records
-struct Vel3 { Vel b[3]; };
-LLD Vel vel_get(const Vel3& v, int i) { return v.b[i]; }
-LLD void vel_set(Vel3& v, int i, Vel x) { v.b[i] = x; }
+struct Vel3 { Vel b0, b1, b2; };
+LLD Vel vel_get(const Vel3& v, int i) {
+    Vel r = v.b0;
+    switch (i) { case 1: r = v.b1; break; case 2: r = v.b2; break; default: break; }
+    return r;
+}
+LLD void vel_set(Vel3& v, int i, Vel x) {
+    switch (i) { case 0: v.b0 = x; break; case 1: v.b1 = x; break; default: v.b2 = x; break; }
+}
 
 LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
     s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
@@ -326,65 +336,73 @@ LLD void cs_apply2(const VConstraint& vc, V2 x, V2 a, V2 normal, V2& vB, float& 
     cp1.normalImpulse = x.x; cp2.normalImpulse = x.y;
 }
 
-LLD void cs_solve_velocity(CSolver& s, Vel3& vel) {  // b2ContactSolver::SolveVelocityConstraints
-    for (int i = 0; i < s.count; ++i) {
-        VConstraint& vc = s.vc[i * s.vs];
-        const float mB = vc.invMassB, iB = vc.invIB;
-        const int pointCount = vc.pointCount;
-        const Vel velB = vel_get(vel, vc.indexB);
-        V2 vB = velB.v; float wB = velB.w;
-        V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
-        const float friction = vc.friction;
-        for (int j = 0; j < pointCount; ++j) {
-            VCPoint& vcp = vc.points[j];
-            V2 dv = vB + cross_sv(wB, vcp.rB);
-            float vt = dot(dv, tangent) - 0.0f;
-            float lambda = vcp.tangentMass * (-vt);
-            float maxFriction = friction * vcp.normalImpulse;
-            float newImpulse = fclamp(vcp.tangentImpulse + lambda, -maxFriction, maxFriction);
-            lambda = newImpulse - vcp.tangentImpulse;
-            vcp.tangentImpulse = newImpulse;
-            V2 P = lambda * tangent;
-            vB = vB + mB * P;
-            wB += iB * cross(vcp.rB, P);
+// b2ContactSolver::SolveVelocityConstraints for ONE constraint acting on the dynamic body whose velocity is velB
+LLD void cs_solve_one(VConstraint& vc, Vel& velB) {
+    const float mB = vc.invMassB, iB = vc.invIB;
+    const int pointCount = vc.pointCount;
+    V2 vB = velB.v; float wB = velB.w;
+    V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
+    const float friction = vc.friction;
+    for (int j = 0; j < pointCount; ++j) {
+        VCPoint& vcp = vc.points[j];
+        V2 dv = vB + cross_sv(wB, vcp.rB);
+        float vt = dot(dv, tangent) - 0.0f;
+        float lambda = vcp.tangentMass * (-vt);
+        float maxFriction = friction * vcp.normalImpulse;
+        float newImpulse = fclamp(vcp.tangentImpulse + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - vcp.tangentImpulse;
+        vcp.tangentImpulse = newImpulse;
+        V2 P = lambda * tangent;
+        vB = vB + mB * P;
+        wB += iB * cross(vcp.rB, P);
+    }
+    if (pointCount == 1) {
+        VCPoint& vcp = vc.points[0];
+        V2 dv = vB + cross_sv(wB, vcp.rB);
+        float vn = dot(dv, normal);
+        float lambda = -vcp.normalMass * (vn - vcp.velocityBias);
+        float newImpulse = fmax2(vcp.normalImpulse + lambda, 0.0f);
+        lambda = newImpulse - vcp.normalImpulse;
+        vcp.normalImpulse = newImpulse;
+        V2 P = lambda * normal;
+        vB = vB + mB * P;
+        wB += iB * cross(vcp.rB, P);
+    } else {
+        VCPoint& cp1 = vc.points[0];
+        VCPoint& cp2 = vc.points[1];
+        V2 a = mk(cp1.normalImpulse, cp2.normalImpulse);
+        V2 dv1 = vB + cross_sv(wB, cp1.rB);
+        V2 dv2 = vB + cross_sv(wB, cp2.rB);
+        float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
+        V2 b = mk(vn1 - cp1.velocityBias, vn2 - cp2.velocityBias);
+        b = b - mk(vc.k11 * a.x + vc.k12 * a.y, vc.k21 * a.x + vc.k22 * a.y);
+        for (;;) {
+            V2 x = -mk(vc.nm11 * b.x + vc.nm12 * b.y, vc.nm21 * b.x + vc.nm22 * b.y);
+            if (x.x >= 0.0f && x.y >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+            x.x = -cp1.normalMass * b.x; x.y = 0.0f;
+            vn2 = vc.k21 * x.x + b.y;
+            if (x.x >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+            x.x = 0.0f; x.y = -cp2.normalMass * b.y;
+            vn1 = vc.k12 * x.y + b.x;
+            if (x.y >= 0.0f && vn1 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+            x.x = 0.0f; x.y = 0.0f;
+            vn1 = b.x; vn2 = b.y;
+            if (vn1 >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
+            break;
         }
-        if (pointCount == 1) {
-            VCPoint& vcp = vc.points[0];
-            V2 dv = vB + cross_sv(wB, vcp.rB);
-            float vn = dot(dv, normal);
-            float lambda = -vcp.normalMass * (vn - vcp.velocityBias);
-            float newImpulse = fmax2(vcp.normalImpulse + lambda, 0.0f);
-            lambda = newImpulse - vcp.normalImpulse;
-            vcp.normalImpulse = newImpulse;
-            V2 P = lambda * normal;
-            vB = vB + mB * P;
-            wB += iB * cross(vcp.rB, P);
-        } else {
-            VCPoint& cp1 = vc.points[0];
-            VCPoint& cp2 = vc.points[1];
-            V2 a = mk(cp1.normalImpulse, cp2.normalImpulse);
-            V2 dv1 = vB + cross_sv(wB, cp1.rB);
-            V2 dv2 = vB + cross_sv(wB, cp2.rB);
-            float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
-            V2 b = mk(vn1 - cp1.velocityBias, vn2 - cp2.velocityBias);
-            b = b - mk(vc.k11 * a.x + vc.k12 * a.y, vc.k21 * a.x + vc.k22 * a.y);
-            for (;;) {
-                V2 x = -mk(vc.nm11 * b.x + vc.nm12 * b.y, vc.nm21 * b.x + vc.nm22 * b.y);
-                if (x.x >= 0.0f && x.y >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-                x.x = -cp1.normalMass * b.x; x.y = 0.0f;
-                vn2 = vc.k21 * x.x + b.y;
-                if (x.x >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-                x.x = 0.0f; x.y = -cp2.normalMass * b.y;
-                vn1 = vc.k12 * x.y + b.x;
-                if (x.y >= 0.0f && vn1 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-                x.x = 0.0f; x.y = 0.0f;
-                vn1 = b.x; vn2 = b.y;
-                if (vn1 >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-                break;
-            }
-        }
-        Vel outB; outB.v = vB; outB.w = wB;
-        vel_set(vel, vc.indexB, outB);
+    }
+    velB.v = vB; velB.w = wB;
+}
+// ... for constraints [i0, i1), all of which act on the SAME dynamic body (island contacts are grouped by body
+// in DFS order), whose velocity lives in the caller's registers
+LLD void cs_solve_velocity_range(CSolver& s, int i0, int i1, Vel& velB) {
+    for (int i = i0; i < i1; ++i) cs_solve_one(s.vc[i * s.vs], velB);
+}
+LLD void cs_solve_one_on(VConstraint& vc, int body, Vel3& vel) {
+    switch (body) {
+    case 0: cs_solve_one(vc, vel.b0); break;
+    case 1: cs_solve_one(vc, vel.b1); break;
+    default: cs_solve_one(vc, vel.b2); break;
     }
 }
 
@@ -584,6 +602,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
 
     // depth-first search with Box2D's stack discipline (ground = 3 on the stack)
     int ibody[3], nb = 0, icontact[kSlots], nc = 0, ijoint[2], nj = 0;
+    int cstart[4] = {0, 0, 0, 0};  // constraints of the q-th visited body: [cstart[q], cstart[q + 1])
     bool jflag[2] = {false, false}, groundFlag = false;
     int stack[6], sc = 0;
     int order[kSlots];
@@ -592,6 +611,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     while (sc > 0) {
         int bi = stack[--sc];
         if (bi == 3) continue;  // static body: in the island, not traversed, contributes nothing
+        cstart[nb] = nc;
         ibody[nb++] = bi;
         w.b[bi].awake = true;
         for (int q = 0; q < n_order; ++q) {
@@ -614,6 +634,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         }
     }
 
+    cstart[nb] = nc;
     Pos pos[3]; Vel3 vel;
     const float h = dt;
     for (int i = 0; i < 3; ++i) {  // all three bodies are always in the island (joints connect them)
@@ -626,6 +647,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         vel_set(vel, i, vi);
     }
 
+    LL_STAMP(2);
     CSolver cs;
     cs_init(cs, mem, w, k, icontact, nc, true, dtRatio);
     cs_init_velocity(cs, w, pos, vel);
@@ -634,28 +656,50 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     const bool leg1_first = ijoint[0] == 1;
     Joint J0 = w.jt[0], J1 = w.jt[1];  // register copies for the 180 sweeps
     if (leg1_first) {
-        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b[0], vel.b[2], dtRatio);
-        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b[0], vel.b[1], dtRatio);
+        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b0, vel.b2, dtRatio);
+        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b0, vel.b1, dtRatio);
     } else {
-        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b[0], vel.b[1], dtRatio);
-        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b[0], vel.b[2], dtRatio);
+        rj_init_velocity(J0, 1, k, pos[0].a, pos[1].a, vel.b0, vel.b1, dtRatio);
+        rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b0, vel.b2, dtRatio);
     }
+    LL_STAMP(3);
+    // the first two contact constraints ride in registers through the sweeps (the LDS copies cannot be kept in
+    // registers by the compiler: every impulse store may alias them); the rest stay in LDS
+    VConstraint r0, r1;
+    int rb0 = -1, rb1 = -1;
+    if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
+    if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
     for (int it = 0; it < 180; ++it) {
         if (leg1_first) {
-            rj_solve_velocity(J1, 1, k, vel.b[0].v, vel.b[0].w, vel.b[2].v, vel.b[2].w, dt, inv_dt);
-            rj_solve_velocity(J0, 0, k, vel.b[0].v, vel.b[0].w, vel.b[1].v, vel.b[1].w, dt, inv_dt);
+            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
+            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
         } else {
-            rj_solve_velocity(J0, 0, k, vel.b[0].v, vel.b[0].w, vel.b[1].v, vel.b[1].w, dt, inv_dt);
-            rj_solve_velocity(J1, 1, k, vel.b[0].v, vel.b[0].w, vel.b[2].v, vel.b[2].w, dt, inv_dt);
+            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
+            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
         }
-        cs_solve_velocity(cs, vel);
+        if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
+        if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
+        if (cs.count > 2) {
+            for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
+                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < cs.count ? cstart[q + 1] : cs.count;
+                if (c0 >= c1) continue;
+                switch (ibody[q]) {
+                case 0: cs_solve_velocity_range(cs, c0, c1, vel.b0); break;
+                case 1: cs_solve_velocity_range(cs, c0, c1, vel.b1); break;
+                default: cs_solve_velocity_range(cs, c0, c1, vel.b2); break;
+                }
+            }
+        }
     }
+    if (rb0 >= 0) cs.vc[0] = r0;
+    if (rb1 >= 0) cs.vc[cs.vs] = r1;
+    LL_STAMP(4);
     w.jt[0] = J0; w.jt[1] = J1;
     cs_store_impulses(cs, w);
 
-    integrate_position(pos[0].c, pos[0].a, vel.b[0].v, vel.b[0].w, h);
-    integrate_position(pos[1].c, pos[1].a, vel.b[1].v, vel.b[1].w, h);
-    integrate_position(pos[2].c, pos[2].a, vel.b[2].v, vel.b[2].w, h);
+    integrate_position(pos[0].c, pos[0].a, vel.b0.v, vel.b0.w, h);
+    integrate_position(pos[1].c, pos[1].a, vel.b1.v, vel.b1.w, h);
+    integrate_position(pos[2].c, pos[2].a, vel.b2.v, vel.b2.w, h);
 
     bool positionSolved = false;
     for (int it = 0; it < 60; ++it) {
@@ -676,6 +720,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         body_sync_transform(b);
     }
 
+    LL_STAMP(5);
     float minSleepTime = FLT_MAX;
     for (int q = 0; q < nb; ++q) minSleepTime = sleep_update(w.b[ibody[q]], h, minSleepTime);
     if (minSleepTime >= b2_timeToSleep && positionSolved)
@@ -721,7 +766,9 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
                 V2 ev[2];
                 edge_verts(w, c.edge, ev[0], ev[1]);
                 float beta;
+                LL_STAMP(8);
                 int state = time_of_impact(ev, tab, poly_of(c.body), bB.sw, beta);
+                LL_STAMP(9);
                 if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
                 else alpha = 1.0f;
                 c.toi = alpha;
@@ -763,25 +810,37 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
         }
 
         // b2Island::SolveTOI: positions/velocities of the one dynamic body (slot `dyn` of a 3-entry table)
+        LL_STAMP(10);
         const float sub_dt = (1.0f - minAlpha) * dt;
         Pos pos[3]; Vel3 vel;
         pos[dyn].c = bB.sw.c; pos[dyn].a = bB.sw.a;
-        { Vel vd; vd.v = bB.v; vd.w = bB.w; vel.b[0] = vd; vel.b[1] = vd; vel.b[2] = vd; }  // only slot `dyn` is referenced
+        Vel vd; vd.v = bB.v; vd.w = bB.w;
+        vel.b0 = vd; vel.b1 = vd; vel.b2 = vd;  // cs_init_velocity reads slot `dyn` only
         CSolver cs;
         cs_init(cs, mem, w, k, islandSlots, nc, false, 1.0f);
         for (int i = 0; i < 20; ++i)
             if (cs_solve_position(cs, pos, true)) break;
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
         cs_init_velocity(cs, w, pos, vel);
-        for (int i = 0; i < 180; ++i) cs_solve_velocity(cs, vel);
+        {   // same register residency for the first two constraints (TOI impulses are never stored back)
+            VConstraint r0, r1;
+            const bool h0 = cs.count > 0, h1 = cs.count > 1;
+            if (h0) r0 = cs.vc[0];
+            if (h1) r1 = cs.vc[cs.vs];
+            for (int i = 0; i < 180; ++i) {
+                if (h0) cs_solve_one(r0, vd);
+                if (h1) cs_solve_one(r1, vd);
+                if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
+            }
+        }
         {
             const float h = sub_dt;
-            Vel vd = vel_get(vel, dyn);
             V2 c = pos[dyn].c; float a = pos[dyn].a;
             integrate_position(c, a, vd.v, vd.w, h);
             bB.sw.c = c; bB.sw.a = a; bB.v = vd.v; bB.w = vd.w;
             body_sync_transform(bB);
         }
+        LL_STAMP(11);
         int moved[1], nm = 0;
         if (body_sync_fixtures(w, tab, dyn)) moved[nm++] = dyn;
         for (int s = 0; s < kSlots; ++s)
@@ -803,9 +862,13 @@ LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolve
     const float dt = 1.0f / 50.0f;
     const float inv_dt = 1.0f / dt;
     const float dtRatio = (w.stepped_once ? inv_dt : 0.0f) * dt;
+    LL_STAMP(0);
     collide(w, tab);
+    LL_STAMP(1);
     solve_island(w, tab, k, mem, dt, inv_dt, dtRatio);
+    LL_STAMP(6);
     solve_toi(w, tab, k, mem, dt);
+    LL_STAMP(7);
     w.stepped_once = true;
     for (int i = 0; i < 3; ++i) { w.b[i].force = mk(0.0f, 0.0f); w.b[i].torque = 0.0f; }
 }

@@ -64,7 +64,8 @@ __device__ __forceinline__ void ll_push(const LLDev& d, bool want, uint32_t entr
 // Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
 // stepped here with the register-only fast path (ll_free.h); everything else — and every env the fast path
 // declines or that finished and must auto-reset — goes to the worklist for ll_general_kernel.
-__global__ void __launch_bounds__(kLLBlock)
+template <int OCC>
+__global__ void __launch_bounds__(kLLBlock, OCC)
 ll_free_kernel(LLDev d, LLIo io) {
     __shared__ PolyTab tab;
     stage_tab(tab, d.k);
@@ -126,30 +127,41 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
         World w; EnvRegs e;
         ll_load(d, i, w, e);
         float state[8];
-        if (mode == 0) {
-            if (!e.has_world) {
-                not_reset = true;
-                if (io.rew) io.rew[i] = 0.0f;
-                if (io.done_out) io.done_out[i] = 0;
-                if (io.trunc_out) io.trunc_out[i] = 0;
-                continue;
+        if (mode == 0 && !e.has_world) {
+            not_reset = true;
+            if (io.rew) io.rew[i] = 0.0f;
+            if (io.done_out) io.done_out[i] = 0;
+            if (io.trunc_out) io.trunc_out[i] = 0;
+            continue;
+        }
+        // One inlined copy of the step body serves all three uses: a plain step (pass 0, mode 0), the implicit
+        // step(0) that ends reset() (lunar_lander.rs:911), and the fused auto-reset after a finished step (pass 1).
+        bool need_reset = mode == 1;
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t action = 0u;
+            if (mode == 2) {  // Testable::reset_deterministic: no step
+                const float H = VIEWPORT_H / SCALE;
+                float height[12];
+                for (int t = 0; t < 12; ++t) height[t] = H / 8.0f;  // :1278-1280
+                ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
+                e.step = 1u;
+                ll_observe(w.b[0], w.legs[0], w.legs[1], state);  // :1441
+                break;
+            }
+            if (need_reset) {
+                ll_reset_scene(d, i, w, e, tab);  // reset() up to the implicit step (lunar_lander.rs:727-908)
+            } else {
+                action = io.act[i];
             }
             float reward, d0, d1; uint32_t done;
             ll_dispersion(d, i, e, d0, d1);
-            ll_env_step(w, e, tab, d.k, mem, io.act[i], d0, d1, state, reward, done);
+            ll_env_step(w, e, tab, d.k, mem, action, d0, d1, state, reward, done);
+            if (need_reset) { e.episode += 1u; break; }
             if (io.rew) io.rew[i] = reward;
             if (io.done_out) io.done_out[i] = (uint8_t)done;
             if (io.trunc_out) io.trunc_out[i] = 0;
-            if (d.auto_reset && done) ll_env_reset(d, i, w, e, tab, mem, state);
-        } else if (mode == 1) {
-            ll_env_reset(d, i, w, e, tab, mem, state);
-        } else {
-            const float H = VIEWPORT_H / SCALE;
-            float height[12];
-            for (int t = 0; t < 12; ++t) height[t] = H / 8.0f;  // :1278-1280
-            ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
-            e.step = 1u;
-            ll_observe(w.b[0], w.legs[0], w.legs[1], state);  // :1441
+            if (!(d.auto_reset && done)) break;
+            need_reset = true;
         }
         overflow |= w.overflow;
         ll_store(d, i, w, e);
@@ -218,6 +230,7 @@ struct LunarLanderEnv final : Env {
     void* work_base = nullptr;
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
+    int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
@@ -285,7 +298,11 @@ struct LunarLanderEnv final : Env {
             return MGYM_OK;
         }
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(ll_free_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io);
+        switch (free_occ) {
+        case 1: hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
+        case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
+        default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
+        }
         hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;

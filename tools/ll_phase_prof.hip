@@ -1,0 +1,61 @@
+// tools/ll_phase_prof.hip — diagnostic build of the LunarLander kernels with per-phase wave-cycle stamps
+// (NOT product code; never quote its run time).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_cnt[16];
+__device__ unsigned long long g_blk[4096 * 16];   // per block (wave) of the general kernel: cycles per phase, this launch
+__device__ unsigned long long g_blkcnt[4096 * 16];
+#define LL_STAMP(id) do { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { unsigned long long t_ = __builtin_readcyclecounter(); \
+    if (id != 0 && id != 8) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 4096) { g_blk[blockIdx.x * 16 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 16 + id] += 1; } } s_last = t_; } } while (0)
+static __device__ __shared__ unsigned long long s_last;
+#include "../modurl_gym_amd/csrc/lunar_lander.hip"
+#include <stdio.h>
+#include <vector>
+namespace mgym {
+void set_last_error(const std::string& m) { fprintf(stderr, "%s\n", m.c_str()); }
+int hip_fail(hipError_t e, const char* what, const char*, int) { fprintf(stderr, "HIP %d %s\n", (int)e, what); return 4; }
+Env* make_cartpole() { return nullptr; }
+Env* make_mountaincar(bool) { return nullptr; }
+}
+using namespace mgym;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+int main(int argc, char** argv) {
+    uint64_t n = argc > 1 ? strtoull(argv[1], 0, 0) : (1u << 18);
+    int steps = argc > 2 ? atoi(argv[2]) : 150;
+    LunarLanderEnv env; env.cfg.struct_size = sizeof(mgym_config); env.cfg.flags = MGYM_FLAG_AUTO_RESET; env.cfg.seed = 5; env.cfg.gravity = -10.f;
+    env.cfg.enable_wind = 1; env.cfg.wind_power = 15.f; env.cfg.turbulence_power = 1.5f;
+    env.n = n; env.n_pad = round_up(n, 1024);
+    CK(hipStreamCreate(&env.stream)); CK(hipMalloc((void**)&env.d_err, 4)); CK(hipMemset(env.d_err, 0, 4));
+    env.init();
+    uint32_t* act; float* rew; uint8_t *dn, *tr;
+    CK(hipMalloc((void**)&act, 16 * n * 4)); CK(hipMalloc((void**)&rew, n * 4)); CK(hipMalloc((void**)&dn, n)); CK(hipMalloc((void**)&tr, n));
+    { std::vector<uint32_t> h(16 * n); uint32_t s = 12345; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 3; } CK(hipMemcpy(act, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+    env.reset(nullptr, nullptr, true, nullptr);
+    for (int t = 0; t < 100; ++t) env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);  // reach the steady mix of flight / contact
+    CK(hipStreamSynchronize(env.stream));
+    unsigned long long z[16] = {0};
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), z, sizeof z));
+    static unsigned long long hb[4096 * 16], hc[4096 * 16], zz[4096 * 16];
+    double worst_phase[16] = {0}, worst_cnt[16] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
+    for (int t = 0; t < steps; ++t) {
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), zz, sizeof zz)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blkcnt), zz, sizeof zz));
+        env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);
+        CK(hipStreamSynchronize(env.stream));
+        CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_blk), sizeof hb)); CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_blkcnt), sizeof hc));
+        int wb = -1; double wt = 0;
+        for (int b = 0; b < 4096; ++b) { double tt = 0; for (int q = 0; q < 16; ++q) tt += (double)hb[b * 16 + q]; if (tt > 0) { mean_tot += tt; nwaves++; } if (tt > wt) { wt = tt; wb = b; } }
+        if (wb >= 0) { worst_tot += wt; for (int q = 0; q < 16; ++q) { worst_phase[q] += (double)hb[wb * 16 + q]; worst_cnt[q] += (double)hc[wb * 16 + q]; } }
+    }
+    CK(hipStreamSynchronize(env.stream));
+    unsigned long long p[16], c[16];
+    CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_prof), sizeof p)); CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cnt), sizeof c));
+    const char* names[16] = {"", "collide", "island: DFS+integrate", "island: constraint init + joint init", "island: 180 sweeps", "island: integrate pos + position iters + sync",
+                             "island: sleep + fixture sync + find contacts", "solve_toi total tail", "", "toi: time_of_impact", "toi: advance+update+island build", "toi: substep solve (20 pos + 180 vel)", "", "", "", ""};
+    double tot = 0; for (int i = 0; i < 16; ++i) tot += (double)p[i];
+    printf("wave-cycles by phase over %d steps of %llu envs (general kernel only; shares, not run time):\n", steps, (unsigned long long)n);
+    for (int i = 1; i < 12; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
+    printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
+    for (int i = 1; i < 12; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
+    return 0;
+}
