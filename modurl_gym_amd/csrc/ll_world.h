@@ -591,6 +591,65 @@ LLD float sleep_update(Body& b, float h, float minSleepTime) {
     return fmin2(minSleepTime, b.sleepTime);
 }
 
+// The 180 velocity sweeps of b2Island::Solve as an out-of-line function: the enclosing kernel is large and
+// register-starved, so the hot loop gets its own register allocation (state is copied in, iterated in VGPRs,
+// copied out).  The first two contact constraints ride in registers (their LDS copies could not be kept in
+// registers by the compiler: every impulse store may alias them); the rest stay in LDS.
+#if defined(__HIPCC__)
+#define LL_NOINLINE __device__ __noinline__
+#else
+#define LL_NOINLINE static
+#endif
+LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver& cs, const int* cstart, const int* ibody, int nb,
+                               bool leg1_first, const LLConst& k, float dt, float inv_dt) {
+    Joint J0 = J0_io, J1 = J1_io;
+    Vel3 vel = vel_io;
+    VConstraint r0, r1;
+    int rb0 = -1, rb1 = -1;
+    if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
+    if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
+    for (int it = 0; it < 180; ++it) {
+        if (leg1_first) {
+            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
+            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
+        } else {
+            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
+            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
+        }
+        if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
+        if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
+        if (cs.count > 2) {
+            for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
+                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < cs.count ? cstart[q + 1] : cs.count;
+                if (c0 >= c1) continue;
+                switch (ibody[q]) {
+                case 0: cs_solve_velocity_range(cs, c0, c1, vel.b0); break;
+                case 1: cs_solve_velocity_range(cs, c0, c1, vel.b1); break;
+                default: cs_solve_velocity_range(cs, c0, c1, vel.b2); break;
+                }
+            }
+        }
+    }
+    if (rb0 >= 0) cs.vc[0] = r0;
+    if (rb1 >= 0) cs.vc[cs.vs] = r1;
+    J0_io = J0; J1_io = J1; vel_io = vel;
+}
+
+// the 180 contact-only sweeps of b2Island::SolveTOI on the one dynamic body (impulses are not stored back)
+LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
+    Vel vd = vd_io;
+    VConstraint r0, r1;
+    const bool h0 = cs.count > 0, h1 = cs.count > 1;
+    if (h0) r0 = cs.vc[0];
+    if (h1) r1 = cs.vc[cs.vs];
+    for (int i = 0; i < 180; ++i) {
+        if (h0) cs_solve_one(r0, vd);
+        if (h1) cs_solve_one(r1, vd);
+        if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
+    }
+    vd_io = vd;
+}
+
 // ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
 LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, float inv_dt, float dtRatio) {
     for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
@@ -663,36 +722,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b0, vel.b2, dtRatio);
     }
     LL_STAMP(3);
-    // the first two contact constraints ride in registers through the sweeps (the LDS copies cannot be kept in
-    // registers by the compiler: every impulse store may alias them); the rest stay in LDS
-    VConstraint r0, r1;
-    int rb0 = -1, rb1 = -1;
-    if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
-    if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
-    for (int it = 0; it < 180; ++it) {
-        if (leg1_first) {
-            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
-            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
-        } else {
-            rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
-            rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
-        }
-        if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
-        if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
-        if (cs.count > 2) {
-            for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
-                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < cs.count ? cstart[q + 1] : cs.count;
-                if (c0 >= c1) continue;
-                switch (ibody[q]) {
-                case 0: cs_solve_velocity_range(cs, c0, c1, vel.b0); break;
-                case 1: cs_solve_velocity_range(cs, c0, c1, vel.b1); break;
-                default: cs_solve_velocity_range(cs, c0, c1, vel.b2); break;
-                }
-            }
-        }
-    }
-    if (rb0 >= 0) cs.vc[0] = r0;
-    if (rb1 >= 0) cs.vc[cs.vs] = r1;
+    island_sweeps(J0, J1, vel, cs, cstart, ibody, nb, leg1_first, k, dt, inv_dt);
     LL_STAMP(4);
     w.jt[0] = J0; w.jt[1] = J1;
     cs_store_impulses(cs, w);
@@ -822,17 +852,7 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
             if (cs_solve_position(cs, pos, true)) break;
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
         cs_init_velocity(cs, w, pos, vel);
-        {   // same register residency for the first two constraints (TOI impulses are never stored back)
-            VConstraint r0, r1;
-            const bool h0 = cs.count > 0, h1 = cs.count > 1;
-            if (h0) r0 = cs.vc[0];
-            if (h1) r1 = cs.vc[cs.vs];
-            for (int i = 0; i < 180; ++i) {
-                if (h0) cs_solve_one(r0, vd);
-                if (h1) cs_solve_one(r1, vd);
-                if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
-            }
-        }
+        toi_sweeps(cs, vd);
         {
             const float h = sub_dt;
             V2 c = pos[dyn].c; float a = pos[dyn].a;
