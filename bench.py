@@ -296,6 +296,25 @@ def main():
                 rec["hbm_frac"] = rec["alg_GBps"] * 1e9 / HBM_PEAK
             extra[name] = rec
             st.close()
+        # fused K-step rollout (mgym_rollout): same semantics as K steps, state stays in registers
+        st = Stepper(mg, torch, "cartpole", 1 << 20, local_rank, args.seed + 9, 0, stream, "fused", "eager")
+        rw = torch.empty((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.float32)
+        dn = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        tr = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        for _ in range(4):
+            st.env.rollout_device(st.actions, RING, None, rw, dn, tr)
+        st.env.sync()
+        st.env.timer_start()
+        reps = 50
+        for _ in range(reps):
+            st.env.rollout_device(st.actions, RING, None, rw, dn, tr)
+        ms = st.env.timer_stop()
+        st.env.sync()
+        ksteps = reps * RING
+        extra["cartpole_rollout_K16"] = {"env_steps_per_s": st.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps, "n_envs": st.n,
+                                         "steps": ksteps, "alg_bytes_per_env_step": 10 + 40 / RING,
+                                         "note": "mgym_rollout: K=16 steps per launch, bit-identical to 16 mgym_step calls"}
+        st.close()
         result["extra"] = extra
 
     for s in steppers:

@@ -129,6 +129,14 @@ int mgym_reset_done(mgym_env *env, const uint8_t *done, const uint8_t *truncated
 int mgym_step(mgym_env *env, const void *actions, float *obs_out, float *reward_out,
               uint8_t *done_out, uint8_t *trunc_out);
 
+/* K consecutive Gym::step calls on every env in ONE launch (fused rollout).  Results are
+ * identical to K calls of mgym_step with the same per-step action columns, including the
+ * MGYM_FLAG_AUTO_RESET behaviour between steps; for CartPole/MountainCar the state stays in registers
+ * across the K steps, so per-step HBM traffic is the action read and the reward/flag writes only.
+ * actions: [K][n_envs]; reward_out/done_out/trunc_out: [K][n_envs] or NULL; obs_out: [K][obs_dim][n_envs] or NULL. */
+int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, float *reward_out,
+                 uint8_t *done_out, uint8_t *trunc_out);
+
 /* Zero-copy view of the engine-owned current observation, SoA with column stride *col_stride
  * floats (for CartPole/MountainCar the state columns ARE the observation — `self.state.clone()`,
  * cartpole.rs:301).  Valid until the handle is destroyed; contents follow the stream order. */

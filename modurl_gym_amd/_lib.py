@@ -44,6 +44,7 @@ PROTOTYPES = {
     "mgym_reset_done": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mgym_reset_deterministic": (C.c_int, [_vp, _vp]),
     "mgym_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mgym_rollout": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "mgym_observation": (C.c_int, [_vp, C.POINTER(_vp), _u64p]),
     "mgym_get_state": (C.c_int, [_vp, _vp]),
     "mgym_set_state": (C.c_int, [_vp, _vp]),

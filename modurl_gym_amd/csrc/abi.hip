@@ -220,6 +220,14 @@ int mgym_step(mgym_env* env, const void* actions, float* obs_out, float* reward_
     return e->step(actions, obs_out, reward_out, done_out, trunc_out);
 }
 
+int mgym_rollout(mgym_env* env, const void* actions, int32_t K, float* obs_out, float* reward_out, uint8_t* done_out,
+                 uint8_t* trunc_out) {
+    ENV_OR_FAIL(env);
+    if (K < 0) return bad_arg("mgym_rollout: K < 0");
+    if (!actions && e->n && K) return bad_arg("mgym_rollout: actions is NULL");
+    return e->rollout(actions, K, obs_out, reward_out, done_out, trunc_out);
+}
+
 int mgym_observation(mgym_env* env, const float** obs, uint64_t* col_stride) {
     ENV_OR_FAIL(env);
     if (!obs || !col_stride) return bad_arg("mgym_observation: NULL out pointer");

@@ -275,6 +275,83 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
     }
 }
 
+// Fused K-step rollout (mgym_rollout): one lane keeps its 4 environments in registers for K steps; per step it
+// reads one 16-B action word and writes reward / done / truncated (and the observation if asked).  Identical to K
+// launches of cartpole_step_kernel<4, RMODE, NT> by construction: same per-env function, same reset compaction.
+template <int RMODE>
+__global__ void __launch_bounds__(kBlock)
+cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, int K, float* __restrict__ obs_out, float* __restrict__ rew,
+                        uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    __shared__ ResetScratch lds_[1];
+    constexpr uint64_t kPerBlock = (uint64_t)kBlock * 4;
+    bool bad = false;
+    for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+        const bool in = i0 < d.n;  // n % 4 == 0 is required by the host wrapper
+        CartPoleLane s[4];
+        if (in) {
+            float4 vx = *reinterpret_cast<const float4*>(d.x + i0), vxd = *reinterpret_cast<const float4*>(d.xd + i0);
+            float4 vth = *reinterpret_cast<const float4*>(d.th + i0), vthd = *reinterpret_cast<const float4*>(d.thd + i0);
+            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr + i0);
+            s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x}; s[1] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
+            s[2] = {vx.z, vxd.z, vth.z, vthd.z, vc.z}; s[3] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
+        } else {
+            for (int k = 0; k < 4; ++k) s[k] = {0.f, 0.f, 0.f, 0.f, 0u};
+        }
+        for (int t = 0; t < K; ++t) {
+            const uint64_t off = (uint64_t)t * d.n + i0;
+            uint32_t a[4] = {0u, 0u, 0u, 0u}, dn[4], tr[4];
+            float r[4];
+            if (in) { u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(act + off)); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cartpole_step_one(d.p, s[k], a[k], r[k], dn[k], tr[k], bad);
+            if (RMODE == 2) {  // same LDS compaction as cartpole_step_kernel
+                ResetScratch& lds = lds_[0];
+                if (threadIdx.x == 0) lds.count = 0;
+                __syncthreads();
+                uint32_t slot[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    slot[k] = 0xffffffffu;
+                    if (in && (dn[k] | tr[k])) { slot[k] = atomicAdd(&lds.count, 1u); lds.idx[slot[k]] = (uint16_t)(threadIdx.x * 4 + k); }
+                }
+                __syncthreads();
+                const uint32_t cnt = lds.count;
+                for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) {
+                    CartPoleLane f;
+                    cartpole_reset_one(d, base + lds.idx[j], f);
+                    lds.fresh[j][0] = f.x; lds.fresh[j][1] = f.xd; lds.fresh[j][2] = f.th; lds.fresh[j][3] = f.thd;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (slot[k] != 0xffffffffu) {
+                        s[k].x = lds.fresh[slot[k]][0]; s[k].xd = lds.fresh[slot[k]][1]; s[k].th = lds.fresh[slot[k]][2]; s[k].thd = lds.fresh[slot[k]][3];
+                        s[k].ctr = 0u;
+                    }
+            }
+            if (in) {
+                if (rew) st4<true>(rew + off, r[0], r[1], r[2], r[3]);
+                if (done_out) st1u<true>(reinterpret_cast<uint32_t*>(done_out + off), dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24));
+                if (trunc_out) st1u<true>(reinterpret_cast<uint32_t*>(trunc_out + off), tr[0] | (tr[1] << 8) | (tr[2] << 16) | (tr[3] << 24));
+                if (obs_out) {
+                    float* o = obs_out + (uint64_t)t * 4 * d.n + i0;
+                    st4<true>(o, s[0].x, s[1].x, s[2].x, s[3].x); st4<true>(o + d.n, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
+                    st4<true>(o + 2 * d.n, s[0].th, s[1].th, s[2].th, s[3].th); st4<true>(o + 3 * d.n, s[0].thd, s[1].thd, s[2].thd, s[3].thd);
+                }
+            }
+        }
+        if (in) {
+            st4<kNtStores>(d.x + i0, s[0].x, s[1].x, s[2].x, s[3].x); st4<kNtStores>(d.xd + i0, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
+            st4<kNtStores>(d.th + i0, s[0].th, s[1].th, s[2].th, s[3].th); st4<kNtStores>(d.thd + i0, s[0].thd, s[1].thd, s[2].thd, s[3].thd);
+            st4u<kNtStores>(d.ctr + i0, s[0].ctr, s[1].ctr, s[2].ctr, s[3].ctr);
+        }
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
+    }
+}
+
 // Masked reset.  One lane looks at 4 consecutive mask bytes of each mask with a single dword
 // load (2 B/env of traffic); masked envs are compacted through LDS exactly as in the fused
 // path, so one pass of the block's first lanes evaluates Philox for all of them instead of
@@ -431,6 +508,18 @@ struct CartPoleEnv final : Env {
             if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, 0, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
             else hipLaunchKernelGGL((cartpole_step_kernel<1, 0, kNtStores>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);
         }
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        const uint32_t* act = static_cast<const uint32_t*>(actions);
+        bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
+        if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
+        dim3 gv(grid_for(n / 4)), b(kBlock);
+        if (dev.auto_reset) hipLaunchKernelGGL((cartpole_rollout_kernel<2>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
+        else hipLaunchKernelGGL((cartpole_rollout_kernel<0>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

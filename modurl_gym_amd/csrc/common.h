@@ -49,6 +49,16 @@ struct Env {
     virtual int init() = 0;
     virtual int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) = 0;
     virtual int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) = 0;
+    // K fused steps; default: K launches of step() with strided per-step buffers
+    virtual int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) {
+        for (int k = 0; k < K; ++k) {
+            const char* a = static_cast<const char*>(actions) + (size_t)k * n * 4;
+            int st = step(a, obs_out ? obs_out + (size_t)k * obs_dim * n : nullptr, reward ? reward + (size_t)k * n : nullptr,
+                          done ? done + (size_t)k * n : nullptr, trunc ? trunc + (size_t)k * n : nullptr);
+            if (st != MGYM_OK) return st;
+        }
+        return MGYM_OK;
+    }
     virtual int observation(const float** obs, uint64_t* col_stride) = 0;
     virtual int get_state(void* blob) = 0;
     virtual int set_state(const void* blob) = 0;

@@ -168,6 +168,25 @@ class VecEnv:
         _check(self._lib.mgym_step(self._h, _ptr(actions), _ptr(obs_out), _ptr(reward_out), _ptr(done_out),
                                    _ptr(trunc_out)))
 
+    def rollout_device(self, actions, K, obs_out=None, reward_out=None, done_out=None, trunc_out=None):
+        _check(self._lib.mgym_rollout(self._h, _ptr(actions), int(K), _ptr(obs_out), _ptr(reward_out), _ptr(done_out),
+                                      _ptr(trunc_out)))
+
+    def rollout(self, actions):
+        """K fused steps on host arrays: actions [K, n] -> (obs [K, obs_dim, n], reward [K, n], done, trunc)."""
+        a = np.ascontiguousarray(actions, self.action_dtype)
+        K = a.shape[0]
+        assert a.shape == (K, self.n)
+        n = max(self.n, 1)
+        da = DeviceArray.from_numpy(a, self.device) if a.size else DeviceArray(1, self.action_dtype, self.device)
+        do = DeviceArray((K, self.obs_dim, n), np.float32, self.device)
+        dr = DeviceArray((K, n), np.float32, self.device)
+        dd, dt = DeviceArray((K, n), np.uint8, self.device), DeviceArray((K, n), np.uint8, self.device)
+        self.rollout_device(da, K, do, dr, dd, dt)
+        self.sync()
+        sh = lambda x, shape: x.numpy().reshape(-1)[: int(np.prod(shape))].reshape(shape)
+        return (sh(do, (K, self.obs_dim, self.n)), sh(dr, (K, self.n)), sh(dd, (K, self.n)), sh(dt, (K, self.n)))
+
     def observation_device(self):
         p, stride = C.c_void_p(), C.c_uint64()
         _check(self._lib.mgym_observation(self._h, C.byref(p), C.byref(stride)))

@@ -353,3 +353,48 @@ def test_graph_replay_equals_eager():
     env.sync()
     env.graph_destroy(g)
     assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+# ------------------------------------------------------------------ fused K-step rollout -----
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_cartpole_rollout_equals_k_steps(auto_reset):
+    # mgym_rollout(K) == K x mgym_step, bit for bit (fused rollout keeps state in registers)
+    n, K = 8192, 24
+    a = np.random.default_rng(5).integers(0, 2, (K, n)).astype(np.uint32)
+    fused = mg.VecEnv(mg.CARTPOLE, n, seed=17, auto_reset=auto_reset)
+    plain = mg.VecEnv(mg.CARTPOLE, n, seed=17, auto_reset=auto_reset)
+    ref = ora.OracleVec(ora.CARTPOLE, n, seed=17)
+    assert np.array_equal(fused.reset(), plain.reset())
+    ref.reset()
+    obs, rew, done, trunc = fused.rollout(a)
+    for t in range(K):
+        o, r, d, tr = plain.step(a[t])
+        assert np.array_equal(rew[t], r) and np.array_equal(done[t], d) and np.array_equal(trunc[t], tr), f"step {t}"
+        eo, er, ed, et = ref.step(a[t])
+        assert np.array_equal(r, er) and np.array_equal(d, ed)
+        if auto_reset:
+            ref.reset(mask=ed | et)
+            assert np.array_equal(obs[t], ref.get_state()[:4]), f"step {t}: post-reset observation"
+        else:
+            assert np.array_equal(obs[t], eo), f"step {t}"
+    assert np.array_equal(fused.get_state().view(np.uint32), plain.get_state().view(np.uint32))
+    assert np.array_equal(fused.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_rollout_fallback_paths():
+    # families / shapes without a fused kernel fall back to K plain steps with identical results
+    n, K = 1001, 5      # n % 4 != 0 -> fallback
+    env, ref = mg.VecEnv(mg.CARTPOLE, n, seed=3), ora.OracleVec(ora.CARTPOLE, n, seed=3)
+    env.reset(), ref.reset()
+    a = np.random.default_rng(6).integers(0, 2, (K, n)).astype(np.uint32)
+    obs, rew, done, trunc = env.rollout(a)
+    for t in range(K):
+        eo, er, ed, et = ref.step(a[t])
+        assert np.array_equal(obs[t], eo) and np.array_equal(rew[t], er) and np.array_equal(done[t], ed)
+    mc, mref = mg.VecEnv(mg.MOUNTAINCAR, 512, seed=3), ora.OracleVec(ora.MOUNTAINCAR, 512, seed=3)
+    mc.reset(), mref.reset()
+    a = np.random.default_rng(7).integers(0, 3, (K, 512)).astype(np.uint32)
+    obs, rew, done, trunc = mc.rollout(a)
+    for t in range(K):
+        eo, er, ed, et = mref.step(a[t])
+        assert np.array_equal(obs[t], eo) and np.array_equal(rew[t], er)
