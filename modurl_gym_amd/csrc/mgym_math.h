@@ -163,18 +163,17 @@ MG_HD float mg_cosf(float y) {
 }
 
 // sin and cos of the same argument, sharing the range reduction (glibc sincosf:
-// identical per-output arithmetic to sinf/cosf).
-MG_HD void mg_sincosf(float y, float* sp, float* cp) {
+// identical per-output arithmetic to sinf/cosf).  The |x| >= pi/4 paths are kept out of line on the
+// device: the environments' angles are almost always small, and inlining the table reduction into
+// every kernel costs ~30 VGPRs of occupancy on the hot path.
+#if defined(__HIPCC__)
+#define MG_COLD static __host__ __device__ __attribute__((noinline))
+#else
+#define MG_COLD static __attribute__((noinline))
+#endif
+MG_COLD void mg_sincosf_reduced(float y, float* sp, float* cp) {
     double x = y;
-    int n;
-    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
-        double x2 = x * x;
-        if (abstop12(y) < abstop12(0x1p-12f)) { *sp = y; *cp = 1.0f; return; }
-        *sp = sinf_poly(x, x2, false, 0);
-        *cp = sinf_poly(x, x2, false, 1);
-        return;
-    }
-    int q;
+    int n, q;
     if (abstop12(y) < abstop12(120.0f)) {
         x = reduce_fast(x, &n);
         q = n;
@@ -191,6 +190,17 @@ MG_HD void mg_sincosf(float y, float* sp, float* cp) {
     double xs = x * s, x2 = x * x;
     *sp = sinf_poly(xs, x2, neg, n);
     *cp = sinf_poly(xs, x2, neg, n ^ 1);
+}
+MG_HD void mg_sincosf(float y, float* sp, float* cp) {
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        double x = y;
+        double x2 = x * x;
+        if (abstop12(y) < abstop12(0x1p-12f)) { *sp = y; *cp = 1.0f; return; }
+        *sp = sinf_poly(x, x2, false, 0);
+        *cp = sinf_poly(x, x2, false, 1);
+        return;
+    }
+    mg_sincosf_reduced(y, sp, cp);
 }
 
 // ---- expm1f / tanhf: fdlibm (Sun Microsystems) float versions as shipped by glibc ----
