@@ -120,6 +120,21 @@ MG_HD double reduce_large(uint32_t xi, int* np) {
 
 MG_HD double sc_sign(int q) { return (q == 1 || q == 2) ? -1.0 : 1.0; }  // {1,-1,-1,1}[q&3]
 
+#if defined(__HIPCC__)
+#define MG_COLD static __host__ __device__ __attribute__((noinline))
+#else
+#define MG_COLD static __attribute__((noinline))
+#endif
+// |x| >= 120: out of line (rare; the 2/pi table reduction would otherwise cost registers on every hot path)
+MG_COLD float mg_sincosf_large(float y, int want_cos) {
+    if (!(abstop12(y) < abstop12(as_f32(0x7f800000u)))) return y - y;  // inf/nan -> nan
+    uint32_t xi = as_u32(y);
+    int sign = (int)(xi >> 31), n;
+    double x = reduce_large(xi, &n);
+    double s = sc_sign((n + sign) & 3);
+    return sinf_poly(x * s, x * x, ((n + sign) & 2) != 0, want_cos ? (n ^ 1) : n);
+}
+
 MG_HD float mg_sinf(float y) {
     double x = y;
     int n;
@@ -131,14 +146,8 @@ MG_HD float mg_sinf(float y) {
         x = reduce_fast(x, &n);
         double s = sc_sign(n & 3);
         return sinf_poly(x * s, x * x, (n & 2) != 0, n);
-    } else if (abstop12(y) < abstop12(as_f32(0x7f800000u))) {
-        uint32_t xi = as_u32(y);
-        int sign = (int)(xi >> 31);
-        x = reduce_large(xi, &n);
-        double s = sc_sign((n + sign) & 3);
-        return sinf_poly(x * s, x * x, ((n + sign) & 2) != 0, n);
     }
-    return y - y;  // inf/nan -> nan
+    return mg_sincosf_large(y, 0);
 }
 
 MG_HD float mg_cosf(float y) {
@@ -152,25 +161,14 @@ MG_HD float mg_cosf(float y) {
         x = reduce_fast(x, &n);
         double s = sc_sign(n & 3);
         return sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
-    } else if (abstop12(y) < abstop12(as_f32(0x7f800000u))) {
-        uint32_t xi = as_u32(y);
-        int sign = (int)(xi >> 31);
-        x = reduce_large(xi, &n);
-        double s = sc_sign((n + sign) & 3);
-        return sinf_poly(x * s, x * x, ((n + sign) & 2) != 0, n ^ 1);
     }
-    return y - y;
+    return mg_sincosf_large(y, 1);
 }
 
 // sin and cos of the same argument, sharing the range reduction (glibc sincosf:
 // identical per-output arithmetic to sinf/cosf).  The |x| >= pi/4 paths are kept out of line on the
 // device: the environments' angles are almost always small, and inlining the table reduction into
 // every kernel costs ~30 VGPRs of occupancy on the hot path.
-#if defined(__HIPCC__)
-#define MG_COLD static __host__ __device__ __attribute__((noinline))
-#else
-#define MG_COLD static __attribute__((noinline))
-#endif
 MG_COLD void mg_sincosf_reduced(float y, float* sp, float* cp) {
     double x = y;
     int n, q;
