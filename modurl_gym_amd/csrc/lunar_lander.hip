@@ -109,15 +109,16 @@ ll_free_kernel(LLDev d, LLIo io) {
 
 // General path on a compacted population.  list != nullptr: entries of the worklist (general steps and resets);
 // list == nullptr: every env with `forced` = 0 general step, 1 reset(), 2 Testable::reset_deterministic.
-__global__ void __launch_bounds__(kLLBlock)
+template <int BLK>
+__global__ void __launch_bounds__(BLK)
 ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int forced) {
     __shared__ PolyTab tab;
     // velocity constraints of the contact solver: LDS, one column per lane (31-word records: conflict-free)
-    __shared__ VConstraint s_vc[kSolverCap * kLLBlock];
+    __shared__ VConstraint s_vc[kSolverCap * BLK];
     stage_tab(tab, d.k);
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = kLLBlock; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     bool not_reset = false, overflow = false;
     const uint64_t total = list ? (uint64_t)*count : d.n;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
@@ -230,6 +231,7 @@ struct LunarLanderEnv final : Env {
     void* work_base = nullptr;
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
+    int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the worklist kernel: 32 measured best (3.47 ms vs 3.76 ms at 64, 4.6 ms at 16): shorter per-wave maxima, half the LDS
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
     ~LunarLanderEnv() override {
@@ -273,11 +275,11 @@ struct LunarLanderEnv final : Env {
         if (n == 0) return MGYM_OK;
         LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
         if (all) {
-            hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
+            hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
         } else {
             MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
             hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
-            hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+            hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
@@ -285,7 +287,7 @@ struct LunarLanderEnv final : Env {
     int reset_deterministic(float* obs_out) override {
         if (n == 0) return MGYM_OK;
         LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 2);
+        hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 2);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
@@ -293,7 +295,7 @@ struct LunarLanderEnv final : Env {
         if (n == 0) return MGYM_OK;
         LLIo io{static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc};
         if (general_only) {  // debugging aid (MGYM_LL_GENERAL_ONLY=1): every env through the general kernel
-            hipLaunchKernelGGL(ll_general_kernel, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0);
+            hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0);
             MGYM_HIP(hipGetLastError());
             return MGYM_OK;
         }
@@ -303,7 +305,9 @@ struct LunarLanderEnv final : Env {
         case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         }
-        hipLaunchKernelGGL(ll_general_kernel, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+        if (gen_block == 16) hipLaunchKernelGGL(ll_general_kernel<16>, dim3(work_grid().x * 4), dim3(16), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+        else if (gen_block == 32) hipLaunchKernelGGL(ll_general_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+        else hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
