@@ -148,6 +148,48 @@ mountaincar_step_kernel(MountainCarDev d, const uint32_t* __restrict__ act, floa
     }
 }
 
+// Fused K-step rollout (mgym_rollout): 4 environments per lane stay in registers for K steps; per step one 16-B
+// action word in, reward / done / truncated (and optionally the observation) out.  Same per-env function and the
+// same in-place auto-reset as mountaincar_step_kernel<4, CONT>, hence bit-identical to K separate steps.
+typedef uint32_t mc_u32x4 __attribute__((ext_vector_type(4)));
+template <bool CONT>
+__global__ void __launch_bounds__(kBlock)
+mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, int K, float* __restrict__ obs_out, float* __restrict__ rew,
+                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    const uint64_t groups = d.n / 4;  // n % 4 == 0 is required by the host wrapper
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const uint64_t i0 = g * 4;
+        float4 vp = *reinterpret_cast<const float4*>(d.pos + i0), vv = *reinterpret_cast<const float4*>(d.vel + i0);
+        float ps[4] = {vp.x, vp.y, vp.z, vp.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
+        for (int t = 0; t < K; ++t) {
+            const uint64_t off = (uint64_t)t * d.n + i0;
+            mc_u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const mc_u32x4*>(act + off));
+            uint32_t a[4] = {va.x, va.y, va.z, va.w}, dn[4];
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mountaincar_step_one<CONT>(d.p, ps[k], vs[k], a[k], r[k], dn[k], bad);
+                if (d.auto_reset && dn[k]) mountaincar_reset_one(d, i0 + k, ps[k], vs[k]);
+            }
+            if (rew) nt_store4(rew + off, make_float4(r[0], r[1], r[2], r[3]));
+            if (done_out) __builtin_nontemporal_store(dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24), reinterpret_cast<uint32_t*>(done_out + off));
+            if (trunc_out) __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(trunc_out + off));
+            if (obs_out) {
+                float* o = obs_out + (uint64_t)t * 2 * d.n + i0;
+                nt_store4(o, make_float4(ps[0], ps[1], ps[2], ps[3]));
+                nt_store4(o + d.n, make_float4(vs[0], vs[1], vs[2], vs[3]));
+            }
+        }
+        nt_store4(d.pos + i0, make_float4(ps[0], ps[1], ps[2], ps[3]));
+        nt_store4(d.vel + i0, make_float4(vs[0], vs[1], vs[2], vs[3]));
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 mountaincar_reset_kernel(MountainCarDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int all,
                          int masks_aligned, float* __restrict__ obs_out) {
@@ -257,6 +299,18 @@ struct MountainCarEnv final : Env {
             if (vec_ok) hipLaunchKernelGGL((mountaincar_step_kernel<4, false>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
             else hipLaunchKernelGGL((mountaincar_step_kernel<1, false>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);
         }
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        const uint32_t* act = static_cast<const uint32_t*>(actions);
+        bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
+        if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
+        dim3 gv(grid_for(n / 4)), b(kBlock);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

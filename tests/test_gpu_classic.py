@@ -398,3 +398,23 @@ def test_rollout_fallback_paths():
     for t in range(K):
         eo, er, ed, et = mref.step(a[t])
         assert np.array_equal(obs[t], eo) and np.array_equal(rew[t], er)
+
+
+@pytest.mark.parametrize("name,okind,kind", [("mountain_car", ora.MOUNTAINCAR, mg.MOUNTAINCAR), ("mountain_car_cont", ora.MOUNTAINCAR_CONT, mg.MOUNTAINCAR_CONT)])
+def test_mountain_car_fused_rollout_equals_k_steps(name, okind, kind):
+    n, K = 4096, 40
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 3, (K, n)).astype(np.uint32) if kind == mg.MOUNTAINCAR else rng.uniform(-1.2, 1.2, (K, n)).astype(np.float32)
+    env, ref = mg.VecEnv(kind, n, seed=4, auto_reset=True), ora.OracleVec(okind, n, seed=4)
+    env.reset(), ref.reset()
+    s = ref.get_state(); s[0] = 0.4; s[1] = 0.03; ref.set_state(s); env.set_state(s)   # near the goal: resets happen
+    obs, rew, done, trunc = env.rollout(a)
+    n_done = 0
+    for t in range(K):
+        eo, er, ed, et = ref.step(a[t])
+        assert np.array_equal(rew[t], er) and np.array_equal(done[t], ed) and not trunc[t].any(), f"step {t}"
+        ref.reset(mask=ed)
+        assert np.array_equal(obs[t], ref.get_state()[:2]), f"step {t}"
+        n_done += int(ed.sum())
+    assert n_done > 0
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
