@@ -142,6 +142,10 @@ int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, 
  * cartpole.rs:301).  Valid until the handle is destroyed; contents follow the stream order. */
 int mgym_observation(mgym_env *env, const float **obs, uint64_t *col_stride);
 
+/* Row-major copy of the current observation for consumers that want `[n_envs][obs_dim]` (one row per env,
+ * the shape of the reference's per-env state tensor stacked over envs): out_aos[i * obs_dim + k]. */
+int mgym_observation_aos(mgym_env *env, float *out_aos);
+
 /* Test seam / checkpoint ≙ Testable::set_state (src/testing.rs:15-18).  blob = [state_cols][n_envs]
  * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md. */
 int mgym_get_state(mgym_env *env, void *blob);

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mgym_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgym_rollout": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "mgym_observation": (C.c_int, [_vp, C.POINTER(_vp), _u64p]),
+    "mgym_observation_aos": (C.c_int, [_vp, _vp]),
     "mgym_get_state": (C.c_int, [_vp, _vp]),
     "mgym_set_state": (C.c_int, [_vp, _vp]),
     "mgym_set_dispersion_override": (C.c_int, [_vp, _vp]),

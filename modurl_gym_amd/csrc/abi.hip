@@ -42,6 +42,13 @@ struct DeviceGuard {
 
 using namespace mgym;
 
+// SoA [obs_dim][stride] -> AoS [n][obs_dim]; one lane per env, obs_dim (<= 8) consecutive words per lane
+__global__ void obs_to_aos_kernel(const float* __restrict__ soa, uint64_t stride, int obs_dim, uint64_t n, float* __restrict__ aos) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < obs_dim; ++k) aos[i * obs_dim + k] = soa[(uint64_t)k * stride + i];
+}
+
 struct mgym_env {
     Env* impl;
 };
@@ -232,6 +239,19 @@ int mgym_observation(mgym_env* env, const float** obs, uint64_t* col_stride) {
     ENV_OR_FAIL(env);
     if (!obs || !col_stride) return bad_arg("mgym_observation: NULL out pointer");
     return e->observation(obs, col_stride);
+}
+
+int mgym_observation_aos(mgym_env* env, float* out_aos) {
+    ENV_OR_FAIL(env);
+    if (!out_aos && e->n) return bad_arg("mgym_observation_aos: out is NULL");
+    if (e->n == 0) return MGYM_OK;
+    const float* obs = nullptr;
+    uint64_t stride = 0;
+    int st = e->observation(&obs, &stride);
+    if (st != MGYM_OK) return st;
+    hipLaunchKernelGGL(obs_to_aos_kernel, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream, obs, stride, e->obs_dim, e->n, out_aos);
+    MGYM_HIP(hipGetLastError());
+    return MGYM_OK;
 }
 
 int mgym_get_state(mgym_env* env, void* blob) {

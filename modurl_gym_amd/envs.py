@@ -270,6 +270,13 @@ class VecEnv:
                 _check(self._lib.mgym_memcpy_d2h(self.device, out[k].ctypes.data, p + 4 * k * stride, 4 * self.n))
         return out
 
+    def observation_aos(self):
+        """row-major [n, obs_dim] copy of the current observation (mgym_observation_aos)"""
+        d = DeviceArray((max(self.n, 1), self.obs_dim), np.float32, self.device)
+        _check(self._lib.mgym_observation_aos(self._h, d.ptr))
+        self.sync()
+        return d.numpy()[: self.n]
+
     @property
     def state_cols(self):
         return get_spec(self.kind).state_cols

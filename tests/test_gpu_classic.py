@@ -418,3 +418,13 @@ def test_mountain_car_fused_rollout_equals_k_steps(name, okind, kind):
         n_done += int(ed.sum())
     assert n_done > 0
     assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_observation_aos_is_the_transposed_soa_view():
+    for kind, nact in ((mg.CARTPOLE, 2), (mg.MOUNTAINCAR, 3), (mg.LUNARLANDER, 4)):
+        env = mg.VecEnv(kind, 1000, seed=2)
+        env.reset()
+        obs, *_ = env.step(np.random.default_rng(0).integers(0, nact, 1000).astype(np.uint32))
+        aos = env.observation_aos()
+        assert aos.shape == (1000, env.obs_dim) and np.array_equal(aos, obs.T)
+        assert np.array_equal(env.observation(), obs)
