@@ -276,6 +276,49 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and (args.workload in ALG_BYTES or args.workload == "lunar_lander"):
         result["cpu_baseline"] = cpu_baseline(args.workload, n, args.seed)
 
+    mixed_rec = None
+    if not args.no_extra and args.workload == "cartpole" and args.envs is None:
+        # BASELINE configs[4] at this N (north_star: "steps/sec reported at 1/2/4/8 GPUs on the 8M-env mixed batch"):
+        # 524288 CartPole + 262144 MountainCar + 262144 LunarLander per GPU, measured on EVERY rank after the
+        # headline region (never part of `value`).  Every rank reaches both collectives even if its run raised.
+        msteps, mwarm, m_el, m_err = 64, 320, -1.0, None
+        try:
+            mpop, mst, mbase = mg.mixed_population(1 << 20), [], 0
+            for name, cnt in mpop.items():
+                mst.append(Stepper(mg, torch, name, cnt, local_rank, args.seed + 3, mbase + rank * cnt, stream, "fused", args.launch))
+                mbase += world * cnt
+            for st in mst:
+                st.run(mwarm)          # LunarLander needs a few hundred steps to reach its steady contact mix
+            for st in mst:
+                st.env.sync()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            m_err = repr(e)
+        barrier()
+        if m_err is None:
+            try:
+                t0 = time.perf_counter()
+                for st in mst:
+                    st.run(msteps)
+                torch.cuda.synchronize()
+                m_el = time.perf_counter() - t0
+                for st in mst:
+                    st.env.sync()
+                    st.close()
+            except Exception as e:  # noqa: BLE001
+                m_err, m_el = repr(e), -1.0
+        if dist is not None:
+            t = torch.tensor([m_el, -m_el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            m_el = float(t[0]) if float(t[1]) < 0 else -1.0   # any rank failing (its -m_el = +1) voids the figure
+        if m_el > 0:
+            mixed_rec = {"env_steps_per_s": (1 << 20) * world * msteps / m_el, "ms_per_step": 1e3 * m_el / msteps,
+                         "n_envs_total": (1 << 20) * world, "n_gpus": world, "steps": msteps, "warmup": mwarm,
+                         "per_gpu": "524288 CartPole + 262144 MountainCar + 262144 LunarLander (wind on), fused auto-reset",
+                         "scaling": "weak", "note": "max over ranks, barrier before; LunarLander dominates the step time"}
+        else:
+            mixed_rec = {"error": m_err or "failed on another rank"}
+
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "cartpole" and args.envs is None:
         # the other BASELINE configs, measured AFTER the timed region (never the headline `value`)
         extra = {}
@@ -315,7 +358,29 @@ def main():
                                          "steps": ksteps, "alg_bytes_per_env_step": 10 + 40 / RING,
                                          "note": "mgym_rollout: K=16 steps per launch, bit-identical to 16 mgym_step calls"}
         st.close()
+        # the step either side of the path: a torch policy produces the actions on the same
+        # stream, the engine steps, the next observation feeds the policy — no host synchronisation in the loop
+        tenv = mg.TorchVecEnv(mg.CARTPOLE, 1 << 20, device=local_rank, seed=args.seed + 11, auto_reset=True)
+        w = torch.tensor([0.1, 0.5, 1.0, 1.0], device=tenv.device)
+        with torch.cuda.stream(stream):
+            obs = tenv.reset()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ksteps = 400
+            for t in range(ksteps + 40):
+                if t == 40:
+                    ev0.record(stream)
+                obs = tenv.step((torch.mv(obs.t(), w) > 0).to(torch.int32))[0]
+            ev1.record(stream)
+        ev1.synchronize()
+        tenv.check()
+        ms = ev0.elapsed_time(ev1)
+        extra["cartpole_torch_policy_loop"] = {"env_steps_per_s": tenv.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps,
+                                               "n_envs": tenv.n, "steps": ksteps,
+                                               "note": "per step: torch linear policy (mv, >, cast: 3 eager kernels) + mgym_step, all on one stream"}
+        tenv.close()
         result["extra"] = extra
+    if mixed_rec is not None and rank == 0:
+        result.setdefault("extra", {})["mixed_configs4_this_n"] = mixed_rec
 
     for s in steppers:
         s.close()

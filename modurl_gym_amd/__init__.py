@@ -9,7 +9,8 @@ from .envs import (BadConfigError, CartPoleV1, DeviceArray, InvalidActionError, 
                    MgymError, MountainCarContinuousV0, MountainCarV0, NotResetError, StepInfo, VecEnv,
                    device_count, get_spec)
 from .shard import Shard, mixed_population, shard_range  # noqa: F401
+from .torch_env import TorchVecEnv  # noqa: F401
 
 __all__ = ["CartPoleV1", "MountainCarV0", "MountainCarContinuousV0", "LunarLanderV3", "VecEnv", "StepInfo",
            "DeviceArray", "MgymError", "InvalidActionError", "NotResetError", "BadConfigError", "device_count",
-           "get_spec", "shard_range", "mixed_population", "Shard"]
+           "get_spec", "shard_range", "mixed_population", "Shard", "TorchVecEnv"]

@@ -1,0 +1,88 @@
+"""Torch-ROCm interop: a policy loop that never leaves the GPU or torch's stream,
+checked against the CPU oracle driven with the same actions."""
+import numpy as np
+import pytest
+
+import modurl_gym_amd as mg
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def linear_policy(w):
+    return lambda obs: (torch.einsum("k,kn->n", w, obs) > 0).to(torch.int32)
+
+
+def test_policy_loop_on_torch_stream_matches_oracle():
+    n, T = 40000, 120
+    env = mg.TorchVecEnv(mg.CARTPOLE, n, seed=9, auto_reset=True)
+    ref = ora.OracleVec(ora.CARTPOLE, n, seed=9)
+    w = torch.tensor([0.1, 0.5, -1.0, -1.0], device=env.device)  # pushes the wrong way: episodes end quickly
+    policy = linear_policy(w)
+    side = torch.cuda.Stream(env.device)
+    obs = env.reset()
+    exp = ref.reset()
+    assert np.array_equal(obs.cpu().numpy(), exp)
+    acts, outs = [], []
+    with torch.cuda.stream(side):  # everything below is stream-ordered; no host sync inside the loop
+        side.wait_stream(torch.cuda.default_stream(env.device))
+        for t in range(T):
+            a = policy(obs)
+            obs, rew, done, trunc = env.step(a)
+            acts.append(a.clone())
+            outs.append((obs.clone(), rew.clone(), done.clone(), trunc.clone()))
+    side.synchronize()
+    env.check()
+    finished = 0
+    for t in range(T):
+        a = acts[t].cpu().numpy().astype(np.uint32)
+        e_obs, e_rew, e_done, e_trunc = ref.step(a)
+        g_obs, g_rew, g_done, g_trunc = (x.cpu().numpy() for x in outs[t])
+        assert np.array_equal(g_rew, e_rew) and np.array_equal(g_done, e_done.astype(bool)) and np.array_equal(g_trunc, e_trunc.astype(bool)), t
+        ref.reset(mask=e_done | e_trunc)
+        assert np.array_equal(g_obs, ref.get_state()[:4]), f"step {t}"
+        finished += int((e_done | e_trunc).sum())
+    assert finished > 0  # the fused auto-reset was exercised
+
+
+def test_aos_layout_and_zero_copy_view():
+    n = 3000
+    env = mg.TorchVecEnv(mg.LUNARLANDER, n, seed=3, auto_reset=False, obs_layout="aos", enable_wind=True)
+    obs = env.reset()
+    assert tuple(obs.shape) == (n, 8) and obs.is_contiguous()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for _ in range(5):
+        a = torch.randint(0, 4, (n,), generator=g).to(env.device)  # int64: converted by the wrapper
+        obs, rew, done, trunc = env.step(a)
+    view = env.observation_view()
+    assert tuple(view.shape) == (8, n) and view.data_ptr() == env.env.observation_device()[0]
+    env.check()
+    assert torch.equal(view.t().contiguous(), obs)
+    assert done.dtype == torch.bool and rew.dtype == torch.float32
+
+
+def test_rollout_tensor_equals_steps():
+    n, K = 5000, 12
+    a = torch.randint(0, 3, (K, n), dtype=torch.int32, device="cuda")
+    fused = mg.TorchVecEnv(mg.MOUNTAINCAR, n, seed=2, auto_reset=True)
+    plain = mg.TorchVecEnv(mg.MOUNTAINCAR, n, seed=2, auto_reset=True)
+    fused.reset(), plain.reset()
+    obs, rew, done, trunc = fused.rollout(a)
+    for k in range(K):
+        o, r, d, t = plain.step(a[k])
+        assert torch.equal(obs[k], o) and torch.equal(rew[k], r) and torch.equal(done[k], d) and torch.equal(trunc[k], t)
+    fused.check(), plain.check()
+
+
+def test_argument_checks():
+    env = mg.TorchVecEnv(mg.CARTPOLE, 64, seed=1)
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(63, dtype=torch.int32, device=env.device))
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(64, dtype=torch.int32))  # host tensor
+    with pytest.raises(TypeError):
+        env.step(torch.zeros(64, dtype=torch.float32, device=env.device))
+    with pytest.raises(mg.InvalidActionError):  # cartpole.rs:252
+        env.step(torch.full((64,), 2, dtype=torch.int32, device=env.device), check=True)
