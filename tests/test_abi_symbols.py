@@ -67,3 +67,20 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(mg.MgymError) as ei:
         mg.VecEnv(mg.CARTPOLE, 8)
     assert ei.value.status == _lib.ERR_NO_DEVICE
+
+
+def test_rust_ffi_declarations_cover_the_header():
+    """rust/modurl_gym_mgym/src/sys.rs (source-only: no rustc in the image) must declare every header symbol,
+    with the struct fields of mgym_config / mgym_spec in header order."""
+    sys_rs = open(os.path.join(ROOT, "rust", "modurl_gym_mgym", "src", "sys.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (mgym_[a-z0-9_]+)\s*\(", sys_rs))) == declared_symbols()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mgym.h")).read(), flags=re.S)
+    for struct in ("mgym_config", "mgym_spec"):
+        c_body = re.search(r"typedef struct %s \{(.*?)\}" % struct, header, re.S).group(1)
+        c_fields = [re.sub(r"\[\d+\]", "", f.strip()) for decl in re.findall(r"[a-z0-9_]+_t\s+([^;]+);|float\s+([^;]+);", c_body)
+                    for part in decl if part for f in part.split(",")]
+        r_body = re.search(r"pub struct %s \{(.*?)\}" % struct, sys_rs, re.S).group(1)
+        assert re.findall(r"pub ([a-z0-9_]+):", r_body) == c_fields, struct
+    for name, val in re.findall(r"(MGYM_[A-Z_]+) = (\d+)", header):
+        m = re.search(r"pub const %s: [a-z_0-9]+ = (\d+);" % name, sys_rs)
+        assert m and m.group(1) == val, name
