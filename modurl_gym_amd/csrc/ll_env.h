@@ -41,7 +41,9 @@ struct LLDev {
     const float* disp;  // dispersion override [2][n] or nullptr
     uint64_t n, n_pad, seed, env_id_base;
     uint32_t* err;
-    uint32_t* work_list;   // compacted env indices for the general kernel (n words)
+    // compacted env-index lists built on the device (n words each) and their lengths (count[0..2]):
+    //   0 = general steps, 1 = resets (fast path), 2 = resets the fast path declined (general path)
+    uint32_t* work_list;
     uint32_t* work_count;
     LLConst k;
     int auto_reset;

@@ -223,6 +223,31 @@ LLD Vel vel_get(const Vel3& v, int i) {
 LLD void vel_set(Vel3& v, int i, Vel x) {
     switch (i) { case 0: v.b0 = x; break; case 1: v.b1 = x; break; default: v.b2 = x; break; }
 }
+// branch-free forms for the sweep loop: lanes of one wave hold constraints on different bodies, and a switch
+// would run the whole constraint solve once per distinct body (single-level selects only, one word at a time)
+LLD float sel3f(int i, float a0, float a1, float a2) {
+    float r = a2;
+    r = (i == 1) ? a1 : r;
+    r = (i == 0) ? a0 : r;
+    return r;
+}
+LLD Vel vel_pick(const Vel3& v, int i) {
+    Vel r;
+    r.v.x = sel3f(i, v.b0.v.x, v.b1.v.x, v.b2.v.x);
+    r.v.y = sel3f(i, v.b0.v.y, v.b1.v.y, v.b2.v.y);
+    r.w = sel3f(i, v.b0.w, v.b1.w, v.b2.w);
+    return r;
+}
+LLD void vel_put1(Vel& dst, bool take, const Vel& x) {
+    dst.v.x = take ? x.v.x : dst.v.x;
+    dst.v.y = take ? x.v.y : dst.v.y;
+    dst.w = take ? x.w : dst.w;
+}
+LLD void vel_put(Vel3& v, int i, const Vel& x) {
+    vel_put1(v.b0, i == 0, x);
+    vel_put1(v.b1, i == 1, x);
+    vel_put1(v.b2, i != 0 && i != 1, x);
+}
 
 LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
     s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
@@ -399,11 +424,9 @@ LLD void cs_solve_velocity_range(CSolver& s, int i0, int i1, Vel& velB) {
     for (int i = i0; i < i1; ++i) cs_solve_one(s.vc[i * s.vs], velB);
 }
 LLD void cs_solve_one_on(VConstraint& vc, int body, Vel3& vel) {
-    switch (body) {
-    case 0: cs_solve_one(vc, vel.b0); break;
-    case 1: cs_solve_one(vc, vel.b1); break;
-    default: cs_solve_one(vc, vel.b2); break;
-    }
+    Vel vb = vel_pick(vel, body);
+    cs_solve_one(vc, vb);
+    vel_put(vel, body, vb);
 }
 
 LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::StoreImpulses
@@ -601,9 +624,18 @@ LLD float sleep_update(Body& b, float h, float minSleepTime) {
 #define LL_NOINLINE static
 #endif
 LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver& cs, const int* cstart, const int* ibody, int nb,
-                               bool leg1_first, const LLConst& k, float dt, float inv_dt) {
+                               bool leg1_first, const LLConst& k_in, float dt, float inv_dt) {
     Joint J0 = J0_io, J1 = J1_io;
     Vel3 vel = vel_io;
+    // `k_in` points at the kernel's constant block; read through a pointer inside this loop it would be re-loaded
+    // every sweep (the impulse stores to the LDS constraints may alias it): keep the joint constants in registers
+    LLConst k;
+    k.invMass[0] = k_in.invMass[0]; k.invMass[1] = k_in.invMass[1]; k.invI[0] = k_in.invI[0]; k.invI[1] = k_in.invI[1];
+    k.lowerAngle[0] = k_in.lowerAngle[0]; k.lowerAngle[1] = k_in.lowerAngle[1];
+    k.upperAngle[0] = k_in.upperAngle[0]; k.upperAngle[1] = k_in.upperAngle[1];
+    k.motorSpeed[0] = k_in.motorSpeed[0]; k.motorSpeed[1] = k_in.motorSpeed[1];
+    k.maxMotorTorque = k_in.maxMotorTorque;
+    const int n_cs = cs.count, n_vs = cs.vs;
     VConstraint r0, r1;
     int rb0 = -1, rb1 = -1;
     if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
@@ -618,9 +650,9 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
         }
         if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
         if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
-        if (cs.count > 2) {
+        if (n_cs > 2) {
             for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
-                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < cs.count ? cstart[q + 1] : cs.count;
+                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < n_cs ? cstart[q + 1] : n_cs;
                 if (c0 >= c1) continue;
                 switch (ibody[q]) {
                 case 0: cs_solve_velocity_range(cs, c0, c1, vel.b0); break;
@@ -631,21 +663,38 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
         }
     }
     if (rb0 >= 0) cs.vc[0] = r0;
-    if (rb1 >= 0) cs.vc[cs.vs] = r1;
+    if (rb1 >= 0) cs.vc[n_vs] = r1;
     J0_io = J0; J1_io = J1; vel_io = vel;
 }
 
-// the 180 contact-only sweeps of b2Island::SolveTOI on the one dynamic body (impulses are not stored back)
+// the 180 contact-only sweeps of b2Island::SolveTOI on the one dynamic body (impulses are not stored back).
+// A sweep is a pure function of (body velocity, accumulated impulses); when one sweep leaves every word of that
+// state bit-for-bit unchanged, all later sweeps would too, so the loop stops there with the identical result.
+// One body against static ground usually reaches such a fixed point within a few dozen sweeps (the joints of
+// the full island never do, which is why island_sweeps has no such exit).
 LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
     Vel vd = vd_io;
     VConstraint r0, r1;
     const bool h0 = cs.count > 0, h1 = cs.count > 1;
     if (h0) r0 = cs.vc[0];
     if (h1) r1 = cs.vc[cs.vs];
+    const bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
     for (int i = 0; i < 180; ++i) {
+        const Vel v_before = vd;
+        float n00 = 0.0f, t00 = 0.0f, n01 = 0.0f, t01 = 0.0f, n10 = 0.0f, t10 = 0.0f, n11 = 0.0f, t11 = 0.0f;
+        if (h0) { n00 = r0.points[0].normalImpulse; t00 = r0.points[0].tangentImpulse; n01 = r0.points[1].normalImpulse; t01 = r0.points[1].tangentImpulse; }
+        if (h1) { n10 = r1.points[0].normalImpulse; t10 = r1.points[0].tangentImpulse; n11 = r1.points[1].normalImpulse; t11 = r1.points[1].tangentImpulse; }
         if (h0) cs_solve_one(r0, vd);
         if (h1) cs_solve_one(r1, vd);
         if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
+        if (can_stop) {
+            bool same = as_u32(vd.v.x) == as_u32(v_before.v.x) && as_u32(vd.v.y) == as_u32(v_before.v.y) && as_u32(vd.w) == as_u32(v_before.w);
+            if (h0) same = same && as_u32(n00) == as_u32(r0.points[0].normalImpulse) && as_u32(t00) == as_u32(r0.points[0].tangentImpulse) &&
+                           as_u32(n01) == as_u32(r0.points[1].normalImpulse) && as_u32(t01) == as_u32(r0.points[1].tangentImpulse);
+            if (h1) same = same && as_u32(n10) == as_u32(r1.points[0].normalImpulse) && as_u32(t10) == as_u32(r1.points[0].tangentImpulse) &&
+                           as_u32(n11) == as_u32(r1.points[1].normalImpulse) && as_u32(t11) == as_u32(r1.points[1].tangentImpulse);
+            if (same) break;
+        }
     }
     vd_io = vd;
 }

@@ -34,6 +34,7 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
 constexpr int kSolverCap = 8;            // touching contacts one island may hold (LDS: 8 x 64 lanes x 124 B = 62 KB)
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
+enum { L_GENERAL = 0, L_RESET = 1, L_RESET_SLOW = 2, L_COUNT = 3 };  // device-built lists (LLDev::work_list / work_count)
 
 struct LLIo {
     const uint32_t* act;
@@ -51,14 +52,15 @@ __device__ __forceinline__ void ll_write_obs(const LLDev& d, const LLIo& io, uin
 }
 
 // wave-aggregated append of env indices to the worklist (done-mask style ballot + one atomic per wave)
-__device__ __forceinline__ void ll_push(const LLDev& d, bool want, uint32_t entry) {
+__device__ __forceinline__ void ll_push(const LLDev& d, int which, bool want, uint32_t entry) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;  // lane 0 may be inactive in a 32-lane block's tail
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(d.work_count, (uint32_t)__popcll(mask));
-    base = __shfl(base, 0);
-    if (want) d.work_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    if (lane == leader) base = atomicAdd(d.work_count + which, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) d.work_list[(uint64_t)which * d.n_pad + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
 }
 
 // Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
@@ -101,8 +103,8 @@ ll_free_kernel(LLDev d, LLIo io) {
                 }
             }
         }
-        ll_push(d, to_general, (uint32_t)i);
-        ll_push(d, to_reset, (uint32_t)i | kWorkReset);
+        ll_push(d, L_GENERAL, to_general, (uint32_t)i);
+        ll_push(d, L_RESET, to_reset, (uint32_t)i);
     }
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
 }
@@ -121,8 +123,12 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     bool not_reset = false, overflow = false;
     const uint64_t total = list ? (uint64_t)*count : d.n;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+    // block-uniform trip count (the deferred-reset push below is a wave-level collective)
+    for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = q0 + threadIdx.x;
         uint64_t i = q;
+        bool defer_reset = false;
+        if (q < total) {
         int mode = forced;
         if (list) { uint32_t ent = list[q]; i = ent & ~kWorkReset; mode = (ent & kWorkReset) ? 1 : 0; }
         World w; EnvRegs e;
@@ -133,8 +139,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
             if (io.rew) io.rew[i] = 0.0f;
             if (io.done_out) io.done_out[i] = 0;
             if (io.trunc_out) io.trunc_out[i] = 0;
-            continue;
-        }
+        } else {
         // One inlined copy of the step body serves all three uses: a plain step (pass 0, mode 0), the implicit
         // step(0) that ends reset() (lunar_lander.rs:911), and the fused auto-reset after a finished step (pass 1).
         bool need_reset = mode == 1;
@@ -162,17 +167,65 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
             if (io.done_out) io.done_out[i] = (uint8_t)done;
             if (io.trunc_out) io.trunc_out[i] = 0;
             if (!(d.auto_reset && done)) break;
+            if (list) { defer_reset = true; break; }  // compacted: ll_reset_kernel draws the new episode
             need_reset = true;
         }
         overflow |= w.overflow;
         ll_store(d, i, w, e);
         ll_write_obs(d, io, i, state);
+        }
+        }
+        if (list) ll_push(d, L_RESET, defer_reset, (uint32_t)i);
     }
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
     if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
 }
 
-// masked reset: scan the masks (1-2 B/env) and compact the masked envs into the worklist
+// reset() on a compacted list (or on every env when list == nullptr): draw the new episode's scene
+// (lunar_lander.rs:727-908), then the implicit step(0) that ends reset() (:911-916).  A fresh scene is in free
+// flight, so that step runs on the register-only fast path; if the fast path declines (it never creates a
+// contact) the env goes to the L_RESET_SLOW list and ll_general_kernel redoes the reset on the general path —
+// the scene is a pure function of (seed, env id, episode), and the episode counter only advances on success.
+// Keeping resets out of ll_general_kernel matters because nearly every one of its blocks holds a finishing env:
+// an inline reset made every block pay a second full world step.
+template <int BLK>
+__global__ void __launch_bounds__(BLK)
+ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
+    __shared__ PolyTab tab;
+    stage_tab(tab, d.k);
+    const uint64_t total = list ? (uint64_t)*count : d.n;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {  // block-uniform
+        const uint64_t q = q0 + threadIdx.x;
+        uint64_t i = q;
+        bool slow = false;
+        if (q < total) {
+            if (list) i = list[q];
+            V2 force; float torque;
+            {
+                World w; EnvRegs e;
+                ll_load(d, i, w, e);
+                ll_reset_scene(d, i, w, e, tab);
+                force = w.b[0].force; torque = w.b[0].torque;  // the initial random push (:845-849) is not a state column
+                ll_store(d, i, w, e);
+            }
+            FreeRegs f; EnvRegs e;
+            ll_free_load(d, i, f, e);
+            f.b[0].force = force; f.b[0].torque = torque;
+            float state[8], reward, d0, d1; uint32_t done;
+            ll_dispersion(d, i, e, d0, d1);
+            if (ll_free_env_step(d, i, f, e, tab, 0u, d0, d1, state, reward, done)) {
+                e.episode += 1u;
+                ll_free_store(d, i, f, e);
+                ll_write_obs(d, io, i, state);
+            } else {
+                slow = true;
+            }
+        }
+        ll_push(d, L_RESET_SLOW, slow, (uint32_t)i | kWorkReset);
+    }
+}
+
+// masked reset: scan the masks (1-2 B/env) and compact the masked envs into the reset list
 __global__ void __launch_bounds__(256)
 ll_mask_scan_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -180,7 +233,7 @@ ll_mask_scan_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __re
         const uint64_t i = base + threadIdx.x;
         bool m = false;
         if (i < d.n) m = (m0 && m0[i]) || (m1 && m1[i]);
-        ll_push(d, m, (uint32_t)i | kWorkReset);
+        ll_push(d, L_RESET, m, (uint32_t)i);
     }
 }
 
@@ -249,8 +302,8 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemsetAsync(obs_base, 0, (size_t)8 * n_pad * sizeof(float), stream));
         dev.st = static_cast<uint32_t*>(base);
         dev.obs = static_cast<float*>(obs_base);
-        MGYM_HIP(hipMalloc(&work_base, (size_t)(n_pad + 64) * sizeof(uint32_t)));
-        MGYM_HIP(hipMemsetAsync(work_base, 0, (size_t)(n_pad + 64) * sizeof(uint32_t), stream));
+        MGYM_HIP(hipMalloc(&work_base, (size_t)(L_COUNT * n_pad + 64) * sizeof(uint32_t)));
+        MGYM_HIP(hipMemsetAsync(work_base, 0, (size_t)(L_COUNT * n_pad + 64) * sizeof(uint32_t), stream));
         dev.work_count = static_cast<uint32_t*>(work_base);
         dev.work_list = static_cast<uint32_t*>(work_base) + 64;
         dev.disp = nullptr;
@@ -271,15 +324,22 @@ struct LunarLanderEnv final : Env {
         return dim3((unsigned)(b ? b : 1));
     }
 
+    const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
+    // resets of the envs on the L_RESET list (or of every env): fast path, then the (normally empty) declined list
+    void launch_resets(const LLIo& io, bool all) {
+        if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, list_ptr(L_RESET), (const uint32_t*)dev.work_count + L_RESET);
+        hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, list_ptr(L_RESET_SLOW), (const uint32_t*)dev.work_count + L_RESET_SLOW, 0);
+    }
     int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) override {
         if (n == 0) return MGYM_OK;
         LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
-        if (all) {
+        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
+        if (general_only && all) {  // debugging aid: reset + implicit step on the general path
             hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
         } else {
-            MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
-            hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+            if (!all) hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
+            launch_resets(io, all);
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
@@ -299,15 +359,21 @@ struct LunarLanderEnv final : Env {
             MGYM_HIP(hipGetLastError());
             return MGYM_OK;
         }
-        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, sizeof(uint32_t), stream));
+        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
         switch (free_occ) {
         case 1: hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         }
-        if (gen_block == 16) hipLaunchKernelGGL(ll_general_kernel<16>, dim3(work_grid().x * 4), dim3(16), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
-        else if (gen_block == 32) hipLaunchKernelGGL(ll_general_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
-        else hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, (const uint32_t*)dev.work_list, (const uint32_t*)dev.work_count, 0);
+        const uint32_t* gl = list_ptr(L_GENERAL);
+        const uint32_t* gc = dev.work_count + L_GENERAL;
+        if (gen_block == 16) hipLaunchKernelGGL(ll_general_kernel<16>, dim3(work_grid().x * 4), dim3(16), 0, stream, dev, io, gl, gc, 0);
+        else if (gen_block == 32) hipLaunchKernelGGL(ll_general_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, gl, gc, 0);
+        else hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, gl, gc, 0);
+        if (dev.auto_reset) {  // finished envs were compacted onto L_RESET by both kernels; outputs of the step stay as written
+            LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};
+            launch_resets(rio, false);
+        }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

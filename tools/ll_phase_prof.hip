@@ -4,14 +4,15 @@
 #include <stdint.h>
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_cnt[16];
-__device__ unsigned long long g_blk[4096 * 16];   // per block (wave) of the general kernel: cycles per phase, this launch
-__device__ unsigned long long g_blkcnt[4096 * 16];
+__device__ unsigned long long g_blk[8192 * 16];   // per block (wave) of the general kernel: cycles per phase, this launch
+__device__ unsigned long long g_blkcnt[8192 * 16];
 #define LL_STAMP(id) do { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { unsigned long long t_ = __builtin_readcyclecounter(); \
-    if (id != 0 && id != 8) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 4096) { g_blk[blockIdx.x * 16 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 16 + id] += 1; } } s_last = t_; } } while (0)
+    if (id != 0 && id != 8) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 8192) { g_blk[blockIdx.x * 16 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 16 + id] += 1; } } s_last = t_; } } while (0)
 static __device__ __shared__ unsigned long long s_last;
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
 #include <stdio.h>
 #include <vector>
+#include <algorithm>
 namespace mgym {
 void set_last_error(const std::string& m) { fprintf(stderr, "%s\n", m.c_str()); }
 int hip_fail(hipError_t e, const char* what, const char*, int) { fprintf(stderr, "HIP %d %s\n", (int)e, what); return 4; }
@@ -23,6 +24,7 @@ using namespace mgym;
 int main(int argc, char** argv) {
     uint64_t n = argc > 1 ? strtoull(argv[1], 0, 0) : (1u << 18);
     int steps = argc > 2 ? atoi(argv[2]) : 150;
+    int warm = argc > 3 ? atoi(argv[3]) : 100;
     LunarLanderEnv env; env.cfg.struct_size = sizeof(mgym_config); env.cfg.flags = MGYM_FLAG_AUTO_RESET; env.cfg.seed = 5; env.cfg.gravity = -10.f;
     env.cfg.enable_wind = 1; env.cfg.wind_power = 15.f; env.cfg.turbulence_power = 1.5f;
     env.n = n; env.n_pad = round_up(n, 1024);
@@ -32,11 +34,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&act, 16 * n * 4)); CK(hipMalloc((void**)&rew, n * 4)); CK(hipMalloc((void**)&dn, n)); CK(hipMalloc((void**)&tr, n));
     { std::vector<uint32_t> h(16 * n); uint32_t s = 12345; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 3; } CK(hipMemcpy(act, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
     env.reset(nullptr, nullptr, true, nullptr);
-    for (int t = 0; t < 100; ++t) env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);  // reach the steady mix of flight / contact
+    for (int t = 0; t < warm; ++t) env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);  // reach the steady mix of flight / contact
     CK(hipStreamSynchronize(env.stream));
     unsigned long long z[16] = {0};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), z, sizeof z));
-    static unsigned long long hb[4096 * 16], hc[4096 * 16], zz[4096 * 16];
+    static unsigned long long hb[8192 * 16], hc[8192 * 16], zz[8192 * 16];
+    std::vector<double> all_tot;
     double worst_phase[16] = {0}, worst_cnt[16] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
     for (int t = 0; t < steps; ++t) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), zz, sizeof zz)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blkcnt), zz, sizeof zz));
@@ -44,7 +47,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(env.stream));
         CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_blk), sizeof hb)); CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_blkcnt), sizeof hc));
         int wb = -1; double wt = 0;
-        for (int b = 0; b < 4096; ++b) { double tt = 0; for (int q = 0; q < 16; ++q) tt += (double)hb[b * 16 + q]; if (tt > 0) { mean_tot += tt; nwaves++; } if (tt > wt) { wt = tt; wb = b; } }
+        for (int b = 0; b < 8192; ++b) { double tt = 0; for (int q = 0; q < 16; ++q) tt += (double)hb[b * 16 + q]; if (tt > 0) { mean_tot += tt; nwaves++; all_tot.push_back(tt); } if (tt > wt) { wt = tt; wb = b; } }
         if (wb >= 0) { worst_tot += wt; for (int q = 0; q < 16; ++q) { worst_phase[q] += (double)hb[wb * 16 + q]; worst_cnt[q] += (double)hc[wb * 16 + q]; } }
     }
     CK(hipStreamSynchronize(env.stream));
@@ -57,5 +60,11 @@ int main(int argc, char** argv) {
     for (int i = 1; i < 12; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
     printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
     for (int i = 1; i < 12; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
+    std::sort(all_tot.begin(), all_tot.end());
+    if (!all_tot.empty()) {
+        printf("per-block cycles (all launches): ");
+        for (double q : {0.1, 0.5, 0.9, 0.99, 0.999, 1.0}) printf("p%g=%.0f ", q * 100, all_tot[(size_t)((all_tot.size() - 1) * q)]);
+        printf(" blocks/launch=%.0f\n", (double)all_tot.size() / steps);
+    }
     return 0;
 }
