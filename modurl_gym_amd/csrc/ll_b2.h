@@ -81,7 +81,7 @@ LLD float fmin2(float a, float b) { return a < b ? a : b; }
 LLD float fmax2(float a, float b) { return a > b ? a : b; }
 LLD float fclamp(float a, float lo, float hi) { return fmax2(lo, fmin2(a, hi)); }
 LLD float fabs1(float a) { return a > 0.0f ? a : -a; }
-LLD Rot rot_set(float angle) { Rot q; mg_sincosf(angle, &q.s, &q.c); return q; }
+LLD Rot rot_set(float angle) { Rot q; mg_sincosf_u(angle, &q.s, &q.c); return q; }
 LLD V2 rmul(Rot q, V2 v) { return mk(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
 LLD V2 rmulT(Rot q, V2 v) { return mk(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
 LLD V2 xmul(Xf T, V2 v) { return mk((T.q.c * v.x - T.q.s * v.y) + T.p.x, (T.q.s * v.x + T.q.c * v.y) + T.p.y); }

@@ -249,6 +249,28 @@ LLD void vel_put(Vel3& v, int i, const Vel& x) {
     vel_put1(v.b2, i != 0 && i != 1, x);
 }
 
+struct Pos3 { Pos b0, b1, b2; };
+LLD Pos pos_pick(const Pos3& p, int i) {
+    Pos r;
+    r.c.x = sel3f(i, p.b0.c.x, p.b1.c.x, p.b2.c.x);
+    r.c.y = sel3f(i, p.b0.c.y, p.b1.c.y, p.b2.c.y);
+    r.a = sel3f(i, p.b0.a, p.b1.a, p.b2.a);
+    return r;
+}
+LLD void pos_put1(Pos& dst, bool take, const Pos& x) {
+    dst.c.x = take ? x.c.x : dst.c.x;
+    dst.c.y = take ? x.c.y : dst.c.y;
+    dst.a = take ? x.a : dst.a;
+}
+LLD void pos_put(Pos3& p, int i, const Pos& x) {
+    pos_put1(p.b0, i == 0, x);
+    pos_put1(p.b1, i == 1, x);
+    pos_put1(p.b2, i != 0 && i != 1, x);
+}
+LLD bool pos_same(const Pos& a, const Pos& b) {
+    return as_u32(a.c.x) == as_u32(b.c.x) && as_u32(a.c.y) == as_u32(b.c.y) && as_u32(a.a) == as_u32(b.a);
+}
+
 LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
     s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
     if (count > mem.cap) { w.overflow = true; count = mem.cap; }
@@ -442,28 +464,31 @@ LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::St
 
 // b2ContactSolver::SolvePositionConstraints (toi = false) / SolveTOIPositionConstraints (toi = true; the TOI
 // body is always body B of every constraint in the TOI island, so its masses are kept)
+LLD void pc_solve_one(const PConstraint& pc, bool toi, V2& cB, float& aB, float& minSeparation) {
+    const float mB = pc.invMassB, iB = pc.invIB;
+    for (int j = 0; j < pc.pointCount; ++j) {
+        Xf xfB;
+        xfB.q = rot_set(aB);
+        xfB.p = cB - rmul(xfB.q, pc.localCenterB);
+        V2 normal, point; float separation;
+        psm_init(pc, xfB, j, normal, point, separation);
+        V2 rB = point - cB;
+        minSeparation = fmin2(minSeparation, separation);
+        float C = fclamp((toi ? b2_toiBaumgarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
+        float rnB = cross(rB, normal);
+        float K = mB + iB * rnB * rnB;
+        float impulse = K > 0.0f ? -C / K : 0.0f;
+        V2 P = impulse * normal;
+        cB = cB + mB * P;
+        aB += iB * cross(rB, P);
+    }
+}
 LLD bool cs_solve_position(const CSolver& s, Pos* pos, bool toi) {
     float minSeparation = 0.0f;
     for (int i = 0; i < s.count; ++i) {
         const PConstraint& pc = s.pc[i * s.ps];
-        const float mB = pc.invMassB, iB = pc.invIB;
         V2 cB = pos[pc.indexB].c; float aB = pos[pc.indexB].a;
-        for (int j = 0; j < pc.pointCount; ++j) {
-            Xf xfB;
-            xfB.q = rot_set(aB);
-            xfB.p = cB - rmul(xfB.q, pc.localCenterB);
-            V2 normal, point; float separation;
-            psm_init(pc, xfB, j, normal, point, separation);
-            V2 rB = point - cB;
-            minSeparation = fmin2(minSeparation, separation);
-            float C = fclamp((toi ? b2_toiBaumgarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
-            float rnB = cross(rB, normal);
-            float K = mB + iB * rnB * rnB;
-            float impulse = K > 0.0f ? -C / K : 0.0f;
-            V2 P = impulse * normal;
-            cB = cB + mB * P;
-            aB += iB * cross(rB, P);
-        }
+        pc_solve_one(pc, toi, cB, aB, minSeparation);
         pos[pc.indexB].c = cB; pos[pc.indexB].a = aB;
     }
     return toi ? (minSeparation >= -1.5f * b2_linearSlop) : (minSeparation >= -3.0f * b2_linearSlop);
@@ -699,6 +724,71 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
     vd_io = vd;
 }
 
+// The <=60 position iterations of b2Island::Solve (contacts, then the joints in island order) with the three
+// body positions and the first two position constraints in registers, body selection branch-free.  An iteration
+// is a pure function of the positions: when one leaves them bit-for-bit unchanged without meeting the
+// tolerances, the remaining iterations would repeat it, so the loop ends there with the same result (not solved).
+LLD void pc_solve_on(const PConstraint& pc, Pos3& pos, float& minSeparation) {
+    Pos pb = pos_pick(pos, pc.indexB);
+    pc_solve_one(pc, false, pb.c, pb.a, minSeparation);
+    pos_put(pos, pc.indexB, pb);
+}
+LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1, const CSolver& cs, bool leg1_first, const LLConst& k_in) {
+    Pos3 pos = pos_io;
+    LLConst k;
+    k.invMass[0] = k_in.invMass[0]; k.invMass[1] = k_in.invMass[1]; k.invI[0] = k_in.invI[0]; k.invI[1] = k_in.invI[1];
+    k.lowerAngle[0] = k_in.lowerAngle[0]; k.lowerAngle[1] = k_in.lowerAngle[1];
+    k.upperAngle[0] = k_in.upperAngle[0]; k.upperAngle[1] = k_in.upperAngle[1];
+    k.localCenter[0] = k_in.localCenter[0]; k.localCenter[1] = k_in.localCenter[1];
+    k.localAnchorB[0] = k_in.localAnchorB[0]; k.localAnchorB[1] = k_in.localAnchorB[1];
+    const int n_cs = cs.count, n_ps = cs.ps;
+    PConstraint q0, q1;
+    const bool h0 = n_cs > 0, h1 = n_cs > 1;
+    if (h0) q0 = cs.pc[0];
+    if (h1) q1 = cs.pc[n_ps];
+    bool solved = false;
+    for (int it = 0; it < 60; ++it) {
+        const Pos3 before = pos;
+        float minSeparation = 0.0f;
+        if (h0) pc_solve_on(q0, pos, minSeparation);
+        if (h1) pc_solve_on(q1, pos, minSeparation);
+        for (int i = 2; i < n_cs; ++i) pc_solve_on(cs.pc[i * n_ps], pos, minSeparation);
+        const bool contactsOkay = minSeparation >= -3.0f * b2_linearSlop;
+        bool okA, okB;
+        if (leg1_first) {
+            okA = rj_solve_position(J1, 1, k, pos.b0, pos.b2);
+            okB = rj_solve_position(J0, 0, k, pos.b0, pos.b1);
+        } else {
+            okA = rj_solve_position(J0, 0, k, pos.b0, pos.b1);
+            okB = rj_solve_position(J1, 1, k, pos.b0, pos.b2);
+        }
+        if (contactsOkay && okA && okB) { solved = true; break; }
+        if (pos_same(before.b0, pos.b0) && pos_same(before.b1, pos.b1) && pos_same(before.b2, pos.b2)) break;
+    }
+    pos_io = pos;
+    return solved;
+}
+
+// the <=20 position iterations of b2Island::SolveTOI: every constraint acts on the one dynamic body
+LL_NOINLINE void toi_position(const CSolver& cs, Pos& p_io) {
+    Pos p = p_io;
+    const int n_cs = cs.count, n_ps = cs.ps;
+    PConstraint q0, q1;
+    const bool h0 = n_cs > 0, h1 = n_cs > 1;
+    if (h0) q0 = cs.pc[0];
+    if (h1) q1 = cs.pc[n_ps];
+    for (int it = 0; it < 20; ++it) {
+        const Pos before = p;
+        float minSeparation = 0.0f;
+        if (h0) pc_solve_one(q0, true, p.c, p.a, minSeparation);
+        if (h1) pc_solve_one(q1, true, p.c, p.a, minSeparation);
+        for (int i = 2; i < n_cs; ++i) pc_solve_one(cs.pc[i * n_ps], true, p.c, p.a, minSeparation);
+        if (minSeparation >= -1.5f * b2_linearSlop) break;
+        if (pos_same(before, p)) break;
+    }
+    p_io = p;
+}
+
 // ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
 LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, float inv_dt, float dtRatio) {
     for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
@@ -780,16 +870,11 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     integrate_position(pos[1].c, pos[1].a, vel.b1.v, vel.b1.w, h);
     integrate_position(pos[2].c, pos[2].a, vel.b2.v, vel.b2.w, h);
 
-    bool positionSolved = false;
-    for (int it = 0; it < 60; ++it) {
-        bool contactsOkay = cs_solve_position(cs, pos, false);
-        bool jointsOkay = true;
-        for (int i = 0; i < nj; ++i) {
-            const int jj = ijoint[i];
-            bool jointOkay = rj_solve_position(w.jt[jj], jj, k, pos[0], pos[1 + jj]);
-            jointsOkay = jointsOkay && jointOkay;
-        }
-        if (contactsOkay && jointsOkay) { positionSolved = true; break; }
+    bool positionSolved;
+    {
+        Pos3 p3; p3.b0 = pos[0]; p3.b1 = pos[1]; p3.b2 = pos[2];
+        positionSolved = island_position(p3, J0, J1, cs, leg1_first, k);
+        pos[0] = p3.b0; pos[1] = p3.b1; pos[2] = p3.b2;
     }
 
     for (int i = 0; i < 3; ++i) {
@@ -897,8 +982,11 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
         vel.b0 = vd; vel.b1 = vd; vel.b2 = vd;  // cs_init_velocity reads slot `dyn` only
         CSolver cs;
         cs_init(cs, mem, w, k, islandSlots, nc, false, 1.0f);
-        for (int i = 0; i < 20; ++i)
-            if (cs_solve_position(cs, pos, true)) break;
+        {
+            Pos pd = pos[dyn];
+            toi_position(cs, pd);
+            pos[dyn] = pd;
+        }
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
         cs_init_velocity(cs, w, pos, vel);
         toi_sweeps(cs, vd);

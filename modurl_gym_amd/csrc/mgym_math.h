@@ -201,6 +201,42 @@ MG_HD void mg_sincosf(float y, float* sp, float* cp) {
     mg_sincosf_reduced(y, sp, cp);
 }
 
+// Same results as mg_sincosf, arranged for lock-step execution (LunarLander: a wave's lanes hold angles on both
+// sides of pi/4 and in different quadrants, so every branch of the routine above runs for every wave).  For
+// |x| < 120 the range reduction is applied unconditionally — below pi/4 it yields n = 0 and x - 0*pi/2 = x, i.e.
+// exactly the small-argument path — both polynomials are evaluated once, the quadrant swaps/negates them by
+// select (negating every cosine coefficient equals negating the rounded result: round-to-nearest is symmetric).
+// tests/test_math_host.py checks it bit-for-bit against mg_sincosf over the floats.
+MG_HD void mg_sincosf_u(float y, float* sp, float* cp) {
+    if (abstop12(y) < abstop12(120.0f)) {
+        int n;
+        const double xr = reduce_fast((double)y, &n);
+        const double x2 = xr * xr;
+        const double xs = ((n & 3) == 1 || (n & 3) == 2) ? -xr : xr;
+        const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
+                     c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+        const double x3 = xs * x2;
+        const double ts = s2 + x2 * s3;
+        const double x7 = x3 * x2;
+        const double sv = xs + x3 * s1;
+        const float sinv = (float)(sv + x7 * ts);
+        const double x4 = x2 * x2;
+        const double t2 = c3 + x2 * c4;
+        const double t1 = c0 + x2 * c1;
+        const double x6 = x4 * x2;
+        const double cv = t1 + x4 * c2;
+        const double cr = cv + x6 * t2;
+        const float cosv = (float)((n & 2) ? -cr : cr);
+        const bool tiny = abstop12(y) < abstop12(0x1p-12f);
+        const bool odd = (n & 1) != 0;
+        *sp = tiny ? y : (odd ? cosv : sinv);
+        *cp = tiny ? 1.0f : (odd ? sinv : cosv);
+        return;
+    }
+    mg_sincosf_reduced(y, sp, cp);
+}
+
 // ---- expm1f / tanhf: fdlibm (Sun Microsystems) float versions as shipped by glibc ----
 MG_HD float mg_expm1f(float x) {
     const float one = 1.0f, huge = 1.0e+30f, tiny = 1.0e-30f;

@@ -46,7 +46,7 @@ def test_device_math_header_matches_glibc():
     exe = _build("math_host_check.cpp", "math_host_check")
     out = subprocess.run([exe, "997"], capture_output=True, text=True, check=True).stdout
     rows = {l.split()[0]: dict(kv.split("=") for kv in l.split()[1:]) for l in out.strip().splitlines()}
-    for fn in ("sinf", "cosf", "tanhf", "sincosf_self"):
+    for fn in ("sinf", "cosf", "tanhf", "sincosf_self", "sincosf_uniform_vs_sincosf"):
         assert int(rows[fn]["bad_fast"]) == 0, out      # |x| <= 16: every angle the environments produce
     assert int(rows["sinf"]["bad_large"]) == 0 and int(rows["cosf"]["bad_large"]) == 0
     # 16 < |x| < 120: glibc's FMA ifunc variant may round a handful of inputs differently
