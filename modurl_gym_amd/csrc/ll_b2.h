@@ -360,24 +360,6 @@ LLD void world_manifold(const Manifold& manifold, Xf xfB, V2& normal, V2 points[
     }
 }
 
-// b2PositionSolverManifold::Initialize with xfA = identity
-LLD void psm_init(const PConstraint& pc, Xf xfB, int index, V2& normal, V2& point, float& separation) {
-    if (pc.type == FACE_A) {
-        normal = pc.localNormal;
-        V2 planePoint = pc.localPoint;
-        V2 clipPoint = xmul(xfB, pc.localPoints[index]);
-        separation = dot(clipPoint - planePoint, normal) - b2_polygonRadius - b2_polygonRadius;
-        point = clipPoint;
-    } else {
-        normal = rmul(xfB.q, pc.localNormal);
-        V2 planePoint = xmul(xfB, pc.localPoint);
-        V2 clipPoint = pc.localPoints[index];
-        separation = dot(clipPoint - planePoint, normal) - b2_polygonRadius - b2_polygonRadius;
-        point = clipPoint;
-        normal = -normal;
-    }
-}
-
 struct Pos { V2 c; float a; };
 struct Vel { V2 v; float w; };
 

@@ -384,25 +384,28 @@ LLD void cs_apply2(const VConstraint& vc, V2 x, V2 a, V2 normal, V2& vB, float& 
 }
 
 // b2ContactSolver::SolveVelocityConstraints for ONE constraint acting on the dynamic body whose velocity is velB
+LLD void cs_friction_point(VCPoint& vcp, V2 tangent, float friction, float mB, float iB, V2& vB, float& wB) {
+    V2 dv = vB + cross_sv(wB, vcp.rB);
+    float vt = dot(dv, tangent) - 0.0f;
+    float lambda = vcp.tangentMass * (-vt);
+    float maxFriction = friction * vcp.normalImpulse;
+    float newImpulse = fclamp(vcp.tangentImpulse + lambda, -maxFriction, maxFriction);
+    lambda = newImpulse - vcp.tangentImpulse;
+    vcp.tangentImpulse = newImpulse;
+    V2 P = lambda * tangent;
+    vB = vB + mB * P;
+    wB += iB * cross(vcp.rB, P);
+}
 LLD void cs_solve_one(VConstraint& vc, Vel& velB) {
     const float mB = vc.invMassB, iB = vc.invIB;
     const int pointCount = vc.pointCount;
     V2 vB = velB.v; float wB = velB.w;
     V2 normal = vc.normal, tangent = cross_vs(normal, 1.0f);
     const float friction = vc.friction;
-    for (int j = 0; j < pointCount; ++j) {
-        VCPoint& vcp = vc.points[j];
-        V2 dv = vB + cross_sv(wB, vcp.rB);
-        float vt = dot(dv, tangent) - 0.0f;
-        float lambda = vcp.tangentMass * (-vt);
-        float maxFriction = friction * vcp.normalImpulse;
-        float newImpulse = fclamp(vcp.tangentImpulse + lambda, -maxFriction, maxFriction);
-        lambda = newImpulse - vcp.tangentImpulse;
-        vcp.tangentImpulse = newImpulse;
-        V2 P = lambda * tangent;
-        vB = vB + mB * P;
-        wB += iB * cross(vcp.rB, P);
-    }
+    // points addressed by constant index (a loop over `pointCount` would index the record dynamically and pin it
+    // to scratch memory for the whole sweep loop)
+    if (pointCount > 0) cs_friction_point(vc.points[0], tangent, friction, mB, iB, vB, wB);
+    if (pointCount > 1) cs_friction_point(vc.points[1], tangent, friction, mB, iB, vB, wB);
     if (pointCount == 1) {
         VCPoint& vcp = vc.points[0];
         V2 dv = vB + cross_sv(wB, vcp.rB);
@@ -464,24 +467,40 @@ LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::St
 
 // b2ContactSolver::SolvePositionConstraints (toi = false) / SolveTOIPositionConstraints (toi = true; the TOI
 // body is always body B of every constraint in the TOI island, so its masses are kept)
-LLD void pc_solve_one(const PConstraint& pc, bool toi, V2& cB, float& aB, float& minSeparation) {
+LLD void pc_solve_point(const PConstraint& pc, V2 localPoint, bool toi, V2& cB, float& aB, float& minSeparation) {
     const float mB = pc.invMassB, iB = pc.invIB;
-    for (int j = 0; j < pc.pointCount; ++j) {
-        Xf xfB;
-        xfB.q = rot_set(aB);
-        xfB.p = cB - rmul(xfB.q, pc.localCenterB);
-        V2 normal, point; float separation;
-        psm_init(pc, xfB, j, normal, point, separation);
-        V2 rB = point - cB;
-        minSeparation = fmin2(minSeparation, separation);
-        float C = fclamp((toi ? b2_toiBaumgarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
-        float rnB = cross(rB, normal);
-        float K = mB + iB * rnB * rnB;
-        float impulse = K > 0.0f ? -C / K : 0.0f;
-        V2 P = impulse * normal;
-        cB = cB + mB * P;
-        aB += iB * cross(rB, P);
+    Xf xfB;
+    xfB.q = rot_set(aB);
+    xfB.p = cB - rmul(xfB.q, pc.localCenterB);
+    // b2PositionSolverManifold::Initialize with xfA = identity
+    V2 normal, point; float separation;
+    if (pc.type == FACE_A) {
+        normal = pc.localNormal;
+        V2 planePoint = pc.localPoint;
+        V2 clipPoint = xmul(xfB, localPoint);
+        separation = dot(clipPoint - planePoint, normal) - b2_polygonRadius - b2_polygonRadius;
+        point = clipPoint;
+    } else {
+        normal = rmul(xfB.q, pc.localNormal);
+        V2 planePoint = xmul(xfB, pc.localPoint);
+        V2 clipPoint = localPoint;
+        separation = dot(clipPoint - planePoint, normal) - b2_polygonRadius - b2_polygonRadius;
+        point = clipPoint;
+        normal = -normal;
     }
+    V2 rB = point - cB;
+    minSeparation = fmin2(minSeparation, separation);
+    float C = fclamp((toi ? b2_toiBaumgarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
+    float rnB = cross(rB, normal);
+    float K = mB + iB * rnB * rnB;
+    float impulse = K > 0.0f ? -C / K : 0.0f;
+    V2 P = impulse * normal;
+    cB = cB + mB * P;
+    aB += iB * cross(rB, P);
+}
+LLD void pc_solve_one(const PConstraint& pc, bool toi, V2& cB, float& aB, float& minSeparation) {
+    if (pc.pointCount > 0) pc_solve_point(pc, pc.localPoints[0], toi, cB, aB, minSeparation);  // constant indices: see cs_solve_one
+    if (pc.pointCount > 1) pc_solve_point(pc, pc.localPoints[1], toi, cB, aB, minSeparation);
 }
 LLD bool cs_solve_position(const CSolver& s, Pos* pos, bool toi) {
     float minSeparation = 0.0f;
