@@ -366,8 +366,13 @@ struct Vel { V2 v; float w; };
 // ---- GJK (b2Distance), proxy A = edge (2 vertices, identity transform), proxy B = polygon ---------------
 struct SCache { float metric; int count; uint8_t indexA[3], indexB[3]; };
 struct SVertex { V2 wA, wB, w; float a; int indexA, indexB; };
-struct Simplex { SVertex v[3]; int count; };
+// The simplex vertices are three named records, never an indexed array: a dynamically indexed local array lives in
+// scratch memory on the GPU, and b2Distance sits inside the time-of-impact root finder.
+struct Simplex { SVertex v0, v1, v2; int count; };
 
+LLD V2 edge_vertex(const V2 ev[2], int i) {  // ev[i], i in {0, 1}, without indexing
+    return mk(i ? ev[1].x : ev[0].x, i ? ev[1].y : ev[0].y);
+}
 LLD int support2(const V2 ev[2], V2 d) {  // b2DistanceProxy::GetSupport on the edge
     float v0 = dot(ev[0], d), v1 = dot(ev[1], d);
     return v1 > v0 ? 1 : 0;
@@ -382,21 +387,21 @@ LLD int support_poly(const PolyTab& tab, int pi, V2 d) {
     return bestIndex;
 }
 LLD float simplex_metric(const Simplex& s) {
-    if (s.count == 2) return len(s.v[0].w - s.v[1].w);
-    if (s.count == 3) return cross(s.v[1].w - s.v[0].w, s.v[2].w - s.v[0].w);
+    if (s.count == 2) return len(s.v0.w - s.v1.w);
+    if (s.count == 3) return cross(s.v1.w - s.v0.w, s.v2.w - s.v0.w);
     return 0.0f;
 }
 LLD void simplex_solve2(Simplex& s) {
-    V2 w1 = s.v[0].w, w2 = s.v[1].w, e12 = w2 - w1;
+    V2 w1 = s.v0.w, w2 = s.v1.w, e12 = w2 - w1;
     float d12_2 = -dot(w1, e12);
-    if (d12_2 <= 0.0f) { s.v[0].a = 1.0f; s.count = 1; return; }
+    if (d12_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
     float d12_1 = dot(w2, e12);
-    if (d12_1 <= 0.0f) { s.v[1].a = 1.0f; s.count = 1; s.v[0] = s.v[1]; return; }
+    if (d12_1 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
     float inv_d12 = 1.0f / (d12_1 + d12_2);
-    s.v[0].a = d12_1 * inv_d12; s.v[1].a = d12_2 * inv_d12; s.count = 2;
+    s.v0.a = d12_1 * inv_d12; s.v1.a = d12_2 * inv_d12; s.count = 2;
 }
 LLD void simplex_solve3(Simplex& s) {
-    V2 w1 = s.v[0].w, w2 = s.v[1].w, w3 = s.v[2].w;
+    V2 w1 = s.v0.w, w2 = s.v1.w, w3 = s.v2.w;
     V2 e12 = w2 - w1;
     float w1e12 = dot(w1, e12), w2e12 = dot(w2, e12);
     float d12_1 = w2e12, d12_2 = -w1e12;
@@ -408,93 +413,99 @@ LLD void simplex_solve3(Simplex& s) {
     float d23_1 = w3e23, d23_2 = -w2e23;
     float n123 = cross(e12, e13);
     float d123_1 = n123 * cross(w2, w3), d123_2 = n123 * cross(w3, w1), d123_3 = n123 * cross(w1, w2);
-    if (d12_2 <= 0.0f && d13_2 <= 0.0f) { s.v[0].a = 1.0f; s.count = 1; return; }
+    if (d12_2 <= 0.0f && d13_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
     if (d12_1 > 0.0f && d12_2 > 0.0f && d123_3 <= 0.0f) {
         float inv = 1.0f / (d12_1 + d12_2);
-        s.v[0].a = d12_1 * inv; s.v[1].a = d12_2 * inv; s.count = 2; return;
+        s.v0.a = d12_1 * inv; s.v1.a = d12_2 * inv; s.count = 2; return;
     }
     if (d13_1 > 0.0f && d13_2 > 0.0f && d123_2 <= 0.0f) {
         float inv = 1.0f / (d13_1 + d13_2);
-        s.v[0].a = d13_1 * inv; s.v[2].a = d13_2 * inv; s.count = 2; s.v[1] = s.v[2]; return;
+        s.v0.a = d13_1 * inv; s.v2.a = d13_2 * inv; s.count = 2; s.v1 = s.v2; return;
     }
-    if (d12_1 <= 0.0f && d23_2 <= 0.0f) { s.v[1].a = 1.0f; s.count = 1; s.v[0] = s.v[1]; return; }
-    if (d13_1 <= 0.0f && d23_1 <= 0.0f) { s.v[2].a = 1.0f; s.count = 1; s.v[0] = s.v[2]; return; }
+    if (d12_1 <= 0.0f && d23_2 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
+    if (d13_1 <= 0.0f && d23_1 <= 0.0f) { s.v2.a = 1.0f; s.count = 1; s.v0 = s.v2; return; }
     if (d23_1 > 0.0f && d23_2 > 0.0f && d123_1 <= 0.0f) {
         float inv = 1.0f / (d23_1 + d23_2);
-        s.v[1].a = d23_1 * inv; s.v[2].a = d23_2 * inv; s.count = 2; s.v[0] = s.v[2]; return;
+        s.v1.a = d23_1 * inv; s.v2.a = d23_2 * inv; s.count = 2; s.v0 = s.v2; return;
     }
     float inv = 1.0f / (d123_1 + d123_2 + d123_3);
-    s.v[0].a = d123_1 * inv; s.v[1].a = d123_2 * inv; s.v[2].a = d123_3 * inv; s.count = 3;
+    s.v0.a = d123_1 * inv; s.v1.a = d123_2 * inv; s.v2.a = d123_3 * inv; s.count = 3;
+}
+
+LLD void simplex_read(SVertex& v, int indexA, int indexB, const V2 ev[2], const PolyTab& tab, int pi, Xf xfB) {
+    v.indexA = indexA; v.indexB = indexB;
+    v.wA = edge_vertex(ev, indexA);
+    v.wB = xmul(xfB, tab.v[pi][indexB]);
+    v.w = v.wB - v.wA;
+    v.a = 0.0f;
 }
 
 // b2Distance, useRadii = false
 LLD float gjk_distance(SCache& cache, const V2 ev[2], const PolyTab& tab, int pi, Xf xfB) {
     Simplex sx;
     sx.count = cache.count;  // ReadCache
-    for (int i = 0; i < sx.count; ++i) {
-        SVertex& v = sx.v[i];
-        v.indexA = cache.indexA[i]; v.indexB = cache.indexB[i];
-        v.wA = ev[v.indexA];
-        v.wB = xmul(xfB, tab.v[pi][v.indexB]);
-        v.w = v.wB - v.wA;
-        v.a = 0.0f;
-    }
+    if (sx.count > 0) simplex_read(sx.v0, cache.indexA[0], cache.indexB[0], ev, tab, pi, xfB);
+    if (sx.count > 1) simplex_read(sx.v1, cache.indexA[1], cache.indexB[1], ev, tab, pi, xfB);
+    if (sx.count > 2) simplex_read(sx.v2, cache.indexA[2], cache.indexB[2], ev, tab, pi, xfB);
     if (sx.count > 1) {
         float metric1 = cache.metric, metric2 = simplex_metric(sx);
         if (metric2 < 0.5f * metric1 || 2.0f * metric1 < metric2 || metric2 < b2_epsilon) sx.count = 0;
     }
     if (sx.count == 0) {
-        SVertex& v = sx.v[0];
-        v.indexA = 0; v.indexB = 0;
-        v.wA = ev[0];
-        v.wB = xmul(xfB, tab.v[pi][0]);
-        v.w = v.wB - v.wA;
-        v.a = 1.0f;
+        simplex_read(sx.v0, 0, 0, ev, tab, pi, xfB);
+        sx.v0.a = 1.0f;
         sx.count = 1;
     }
     const int k_maxIters = 20;
-    int saveA[3], saveB[3], saveCount = 0;
+    int saveA0 = 0, saveA1 = 0, saveA2 = 0, saveB0 = 0, saveB1 = 0, saveB2 = 0, saveCount = 0;
     int iter = 0;
     while (iter < k_maxIters) {
         saveCount = sx.count;
-        for (int i = 0; i < saveCount; ++i) { saveA[i] = sx.v[i].indexA; saveB[i] = sx.v[i].indexB; }
+        if (saveCount > 0) { saveA0 = sx.v0.indexA; saveB0 = sx.v0.indexB; }
+        if (saveCount > 1) { saveA1 = sx.v1.indexA; saveB1 = sx.v1.indexB; }
+        if (saveCount > 2) { saveA2 = sx.v2.indexA; saveB2 = sx.v2.indexB; }
         if (sx.count == 2) simplex_solve2(sx);
         else if (sx.count == 3) simplex_solve3(sx);
         if (sx.count == 3) break;
         V2 d;  // GetSearchDirection
-        if (sx.count == 1) d = -sx.v[0].w;
+        if (sx.count == 1) d = -sx.v0.w;
         else {
-            V2 e12 = sx.v[1].w - sx.v[0].w;
-            float sgn = cross(e12, -sx.v[0].w);
+            V2 e12 = sx.v1.w - sx.v0.w;
+            float sgn = cross(e12, -sx.v0.w);
             d = sgn > 0.0f ? cross_sv(1.0f, e12) : cross_vs(e12, 1.0f);
         }
         if (len2(d) < b2_epsilon * b2_epsilon) break;
-        SVertex& vertex = sx.v[sx.count];
+        SVertex vertex;  // the new vertex is slot `count` (1 or 2 here)
         vertex.indexA = support2(ev, -d);
-        vertex.wA = ev[vertex.indexA];
+        vertex.wA = edge_vertex(ev, vertex.indexA);
         vertex.indexB = support_poly(tab, pi, rmulT(xfB.q, d));
         vertex.wB = xmul(xfB, tab.v[pi][vertex.indexB]);
         vertex.w = vertex.wB - vertex.wA;
+        vertex.a = sx.count == 1 ? sx.v1.a : sx.v2.a;  // untouched field of the slot it replaces
+        if (sx.count == 1) sx.v1 = vertex; else sx.v2 = vertex;
         ++iter;
         bool duplicate = false;
-        for (int i = 0; i < saveCount; ++i)
-            if (vertex.indexA == saveA[i] && vertex.indexB == saveB[i]) { duplicate = true; break; }
+        if (saveCount > 0 && vertex.indexA == saveA0 && vertex.indexB == saveB0) duplicate = true;
+        if (saveCount > 1 && vertex.indexA == saveA1 && vertex.indexB == saveB1) duplicate = true;
+        if (saveCount > 2 && vertex.indexA == saveA2 && vertex.indexB == saveB2) duplicate = true;
         if (duplicate) break;
         ++sx.count;
     }
     V2 pointA, pointB;  // GetWitnessPoints
-    if (sx.count == 1) { pointA = sx.v[0].wA; pointB = sx.v[0].wB; }
+    if (sx.count == 1) { pointA = sx.v0.wA; pointB = sx.v0.wB; }
     else if (sx.count == 2) {
-        pointA = sx.v[0].a * sx.v[0].wA + sx.v[1].a * sx.v[1].wA;
-        pointB = sx.v[0].a * sx.v[0].wB + sx.v[1].a * sx.v[1].wB;
+        pointA = sx.v0.a * sx.v0.wA + sx.v1.a * sx.v1.wA;
+        pointB = sx.v0.a * sx.v0.wB + sx.v1.a * sx.v1.wB;
     } else {
-        pointA = sx.v[0].a * sx.v[0].wA + sx.v[1].a * sx.v[1].wA + sx.v[2].a * sx.v[2].wA;
+        pointA = sx.v0.a * sx.v0.wA + sx.v1.a * sx.v1.wA + sx.v2.a * sx.v2.wA;
         pointB = pointA;
     }
     float distance = len(pointA - pointB);
     cache.metric = simplex_metric(sx);  // WriteCache
     cache.count = sx.count;
-    for (int i = 0; i < sx.count; ++i) { cache.indexA[i] = (uint8_t)sx.v[i].indexA; cache.indexB[i] = (uint8_t)sx.v[i].indexB; }
+    if (sx.count > 0) { cache.indexA[0] = (uint8_t)sx.v0.indexA; cache.indexB[0] = (uint8_t)sx.v0.indexB; }
+    if (sx.count > 1) { cache.indexA[1] = (uint8_t)sx.v1.indexA; cache.indexB[1] = (uint8_t)sx.v1.indexB; }
+    if (sx.count > 2) { cache.indexA[2] = (uint8_t)sx.v2.indexA; cache.indexB[2] = (uint8_t)sx.v2.indexB; }
     return distance;
 }
 
@@ -506,7 +517,7 @@ LLD void sep_init(SepFn& f, const SCache& cache, const V2 ev[2], const PolyTab& 
     Xf xfB = sweep_xf(sweepB, t1);
     if (cache.count == 1) {
         f.type = SEP_POINTS;
-        V2 pointA = ev[cache.indexA[0]];
+        V2 pointA = edge_vertex(ev, cache.indexA[0]);
         V2 pointB = xmul(xfB, tab.v[pi][cache.indexB[0]]);
         f.axis = pointB - pointA;
         normalize(f.axis);
@@ -518,12 +529,12 @@ LLD void sep_init(SepFn& f, const SCache& cache, const V2 ev[2], const PolyTab& 
         V2 normal = rmul(xfB.q, f.axis);
         f.localPoint = 0.5f * (localPointB1 + localPointB2);
         V2 pointB = xmul(xfB, f.localPoint);
-        V2 pointA = ev[cache.indexA[0]];
+        V2 pointA = edge_vertex(ev, cache.indexA[0]);
         float s = dot(pointA - pointB, normal);
         if (s < 0.0f) f.axis = -f.axis;
     } else {
         f.type = SEP_FACE_A;
-        V2 localPointA1 = ev[cache.indexA[0]], localPointA2 = ev[cache.indexA[1]];
+        V2 localPointA1 = edge_vertex(ev, cache.indexA[0]), localPointA2 = edge_vertex(ev, cache.indexA[1]);
         f.axis = cross_vs(localPointA2 - localPointA1, 1.0f);
         normalize(f.axis);
         V2 normal = f.axis;
@@ -540,7 +551,7 @@ LLD float sep_find_min(const SepFn& f, const V2 ev[2], const PolyTab& tab, int p
         V2 axisA = f.axis, axisB = rmulT(xfB.q, -f.axis);
         indexA = support2(ev, axisA);
         indexB = support_poly(tab, pi, axisB);
-        V2 pointA = ev[indexA], pointB = xmul(xfB, tab.v[pi][indexB]);
+        V2 pointA = edge_vertex(ev, indexA), pointB = xmul(xfB, tab.v[pi][indexB]);
         return dot(pointB - pointA, f.axis);
     } else if (f.type == SEP_FACE_A) {
         V2 normal = f.axis;
@@ -556,14 +567,14 @@ LLD float sep_find_min(const SepFn& f, const V2 ev[2], const PolyTab& tab, int p
         V2 axisA = -normal;
         indexB = -1;
         indexA = support2(ev, axisA);
-        V2 pointA = ev[indexA];
+        V2 pointA = edge_vertex(ev, indexA);
         return dot(pointA - pointB, normal);
     }
 }
 LLD float sep_evaluate(const SepFn& f, const V2 ev[2], const PolyTab& tab, int pi, const Sweep& sweepB, int indexA, int indexB, float t) {
     Xf xfB = sweep_xf(sweepB, t);
     if (f.type == SEP_POINTS) {
-        V2 pointA = ev[indexA], pointB = xmul(xfB, tab.v[pi][indexB]);
+        V2 pointA = edge_vertex(ev, indexA), pointB = xmul(xfB, tab.v[pi][indexB]);
         return dot(pointB - pointA, f.axis);
     } else if (f.type == SEP_FACE_A) {
         V2 normal = f.axis;
@@ -573,7 +584,7 @@ LLD float sep_evaluate(const SepFn& f, const V2 ev[2], const PolyTab& tab, int p
     } else {
         V2 normal = rmul(xfB.q, f.axis);
         V2 pointB = xmul(xfB, f.localPoint);
-        V2 pointA = ev[indexA];
+        V2 pointA = edge_vertex(ev, indexA);
         return dot(pointA - pointB, normal);
     }
 }
