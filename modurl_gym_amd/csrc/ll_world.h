@@ -9,6 +9,12 @@
 #define LL_STAMP(id)  // diagnostic builds (tools/ll_phase_prof.hip) define this to stamp wave cycles per phase
 #endif
 
+#ifndef LL_DIAG_SWEEP
+#define LL_DIAG_SWEEP_BEGIN(kind)
+#define LL_DIAG_SWEEP(kind, it, ...)   // diagnostic builds hash the sweep state to look for short cycles
+#define LL_DIAG_SWEEP_END(kind)
+#endif
+
 namespace mgym {
 namespace ll {
 
@@ -680,10 +686,14 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     k.motorSpeed[0] = k_in.motorSpeed[0]; k.motorSpeed[1] = k_in.motorSpeed[1];
     k.maxMotorTorque = k_in.maxMotorTorque;
     const int n_cs = cs.count, n_vs = cs.vs;
-    VConstraint r0, r1;
-    int rb0 = -1, rb1 = -1;
+    constexpr int kReg = 4;  // constraints held in registers (the kernel runs at one wave per SIMD: 512 VGPRs per lane)
+    VConstraint r0, r1, r2, r3;
+    int rb0 = -1, rb1 = -1, rb2 = -1, rb3 = -1;
     if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
     if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
+    if (cs.count > 2) { r2 = cs.vc[2 * cs.vs]; rb2 = r2.indexB; }
+    if (cs.count > 3) { r3 = cs.vc[3 * cs.vs]; rb3 = r3.indexB; }
+    LL_DIAG_SWEEP_BEGIN(0);
     for (int it = 0; it < 180; ++it) {
         if (leg1_first) {
             rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
@@ -694,9 +704,11 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
         }
         if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
         if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
-        if (n_cs > 2) {
+        if (rb2 >= 0) cs_solve_one_on(r2, rb2, vel);
+        if (rb3 >= 0) cs_solve_one_on(r3, rb3, vel);
+        if (n_cs > kReg) {
             for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
-                const int c0 = cstart[q] > 2 ? cstart[q] : 2, c1 = cstart[q + 1] < n_cs ? cstart[q + 1] : n_cs;
+                const int c0 = cstart[q] > kReg ? cstart[q] : kReg, c1 = cstart[q + 1] < n_cs ? cstart[q + 1] : n_cs;
                 if (c0 >= c1) continue;
                 switch (ibody[q]) {
                 case 0: cs_solve_velocity_range(cs, c0, c1, vel.b0); break;
@@ -705,9 +717,19 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
                 }
             }
         }
+        LL_DIAG_SWEEP(0, it, n_cs <= 2 && rb2 < 0, vel.b0.v.x, vel.b0.v.y, vel.b0.w, vel.b1.v.x, vel.b1.v.y, vel.b1.w, vel.b2.v.x, vel.b2.v.y, vel.b2.w,
+                      J0.impulse.x, J0.impulse.y, J0.motorImpulse, J0.lowerImpulse, J0.upperImpulse,
+                      J1.impulse.x, J1.impulse.y, J1.motorImpulse, J1.lowerImpulse, J1.upperImpulse,
+                      rb0 >= 0 ? r0.points[0].normalImpulse : 0.0f, rb0 >= 0 ? r0.points[0].tangentImpulse : 0.0f,
+                      rb0 >= 0 && r0.pointCount > 1 ? r0.points[1].normalImpulse : 0.0f, rb0 >= 0 && r0.pointCount > 1 ? r0.points[1].tangentImpulse : 0.0f,
+                      rb1 >= 0 ? r1.points[0].normalImpulse : 0.0f, rb1 >= 0 ? r1.points[0].tangentImpulse : 0.0f,
+                      rb1 >= 0 && r1.pointCount > 1 ? r1.points[1].normalImpulse : 0.0f, rb1 >= 0 && r1.pointCount > 1 ? r1.points[1].tangentImpulse : 0.0f);
     }
+    LL_DIAG_SWEEP_END(0);
     if (rb0 >= 0) cs.vc[0] = r0;
     if (rb1 >= 0) cs.vc[n_vs] = r1;
+    if (rb2 >= 0) cs.vc[2 * n_vs] = r2;
+    if (rb3 >= 0) cs.vc[3 * n_vs] = r3;
     J0_io = J0; J1_io = J1; vel_io = vel;
 }
 
@@ -723,6 +745,7 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
     if (h0) r0 = cs.vc[0];
     if (h1) r1 = cs.vc[cs.vs];
     const bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
+    LL_DIAG_SWEEP_BEGIN(1);
     for (int i = 0; i < 180; ++i) {
         const Vel v_before = vd;
         float n00 = 0.0f, t00 = 0.0f, n01 = 0.0f, t01 = 0.0f, n10 = 0.0f, t10 = 0.0f, n11 = 0.0f, t11 = 0.0f;
@@ -737,9 +760,14 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
                            as_u32(n01) == as_u32(r0.points[1].normalImpulse) && as_u32(t01) == as_u32(r0.points[1].tangentImpulse);
             if (h1) same = same && as_u32(n10) == as_u32(r1.points[0].normalImpulse) && as_u32(t10) == as_u32(r1.points[0].tangentImpulse) &&
                            as_u32(n11) == as_u32(r1.points[1].normalImpulse) && as_u32(t11) == as_u32(r1.points[1].tangentImpulse);
+            LL_DIAG_SWEEP(1, i, true, vd.v.x, vd.v.y, vd.w, h0 ? r0.points[0].normalImpulse : 0.0f, h0 ? r0.points[0].tangentImpulse : 0.0f,
+                          h0 && r0.pointCount > 1 ? r0.points[1].normalImpulse : 0.0f, h0 && r0.pointCount > 1 ? r0.points[1].tangentImpulse : 0.0f,
+                          h1 ? r1.points[0].normalImpulse : 0.0f, h1 ? r1.points[0].tangentImpulse : 0.0f,
+                          h1 && r1.pointCount > 1 ? r1.points[1].normalImpulse : 0.0f, h1 && r1.pointCount > 1 ? r1.points[1].tangentImpulse : 0.0f);
             if (same) break;
         }
     }
+    LL_DIAG_SWEEP_END(1);
     vd_io = vd;
 }
 

@@ -1,6 +1,7 @@
 // tools/ll_phase_prof.hip — diagnostic build of the LunarLander kernels with per-phase wave-cycle stamps
 // (NOT product code; never quote its run time).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
 #include <hip/hip_runtime.h>
+#include <initializer_list>
 #include <stdint.h>
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_cnt[16];
@@ -9,6 +10,14 @@ __device__ unsigned long long g_blkcnt[8192 * 16];
 #define LL_STAMP(id) do { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { unsigned long long t_ = __builtin_readcyclecounter(); \
     if (id != 0 && id != 8) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 8192) { g_blk[blockIdx.x * 16 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 16 + id] += 1; } } s_last = t_; } } while (0)
 static __device__ __shared__ unsigned long long s_last;
+// sweep-state cycle diagnostics: per lane, hash the state after every sweep; record the first sweep at which the
+// hash equals the one 1..4 sweeps earlier (period p), or 180 if never.  g_cyc[kind][period 0..4][bucket of 10 sweeps]
+__device__ unsigned long long g_cyc[2][5][19];
+__device__ inline unsigned long long diag_hash(std::initializer_list<float> w) { unsigned long long h = 1469598103934665603ull; for (float f : w) { h ^= __float_as_uint(f); h *= 1099511628211ull; } return h; }
+#define LL_DIAG_SWEEP 1
+#define LL_DIAG_SWEEP_BEGIN(kind) unsigned long long dh_[4] = {1, 2, 3, 4}; int dper_ = 0, dit_ = 180; bool dok_ = true
+#define LL_DIAG_SWEEP(kind, it, ok, ...) do { dok_ = dok_ && (ok); unsigned long long h_ = diag_hash({__VA_ARGS__}); if (dper_ == 0) { for (int p_ = 0; p_ < 4; ++p_) if (h_ == dh_[p_]) { dper_ = p_ + 1; dit_ = it; break; } } dh_[3] = dh_[2]; dh_[2] = dh_[1]; dh_[1] = dh_[0]; dh_[0] = h_; } while (0)
+#define LL_DIAG_SWEEP_END(kind) do { if (dok_) atomicAdd(&g_cyc[kind][dper_][dit_ / 10], 1ull); } while (0)
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
 #include <stdio.h>
 #include <vector>
@@ -60,6 +69,9 @@ int main(int argc, char** argv) {
     for (int i = 1; i < 12; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
     printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
     for (int i = 1; i < 12; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
+    { unsigned long long cyc[2][5][19]; CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof cyc));
+      for (int k = 0; k < 2; ++k) for (int p = 0; p < 5; ++p) { unsigned long long t = 0; for (int b = 0; b < 19; ++b) t += cyc[k][p][b]; if (!t) continue;
+        printf("%s sweeps, <=2 contacts: period %d (0 = none found) n=%llu; first-detected-at histogram by 10 sweeps:", k ? "toi" : "island", p, t); for (int b = 0; b < 19; ++b) printf(" %llu", cyc[k][p][b]); printf("\n"); } }
     std::sort(all_tot.begin(), all_tot.end());
     if (!all_tot.empty()) {
         printf("per-block cycles (all launches): ");
