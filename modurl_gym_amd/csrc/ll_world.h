@@ -23,6 +23,7 @@ struct Joint {  // b2RevoluteJoint, bodyA = lander (0), bodyB = leg (1 + j)
     // solver temporaries
     V2 rA, rB;
     float K11, K12, K21, K22, angle, axialMass;
+    float invDetK;  // 1/det(K) (or det when it is 0) exactly as b2Mat22::Solve forms it: K is fixed for the whole velocity solve
 };
 
 struct World {
@@ -532,6 +533,11 @@ LLD void rj_init_velocity(Joint& j, int leg, const LLConst& k, float aA, float a
     j.K12 = -j.rA.y * j.rA.x * iA - j.rB.y * j.rB.x * iB;
     j.K21 = j.K12;
     j.K22 = mA + mB + j.rA.x * j.rA.x * iA + j.rB.x * j.rB.x * iB;
+    {
+        float det = j.K11 * j.K22 - j.K12 * j.K21;
+        if (det != 0.0f) det = 1.0f / det;
+        j.invDetK = det;
+    }
     j.axialMass = iA + iB;
     j.axialMass = 1.0f / j.axialMass;  // iA + iB > 0 always
     j.angle = aB - aA - 0.0f;          // referenceAngle = 0
@@ -580,7 +586,8 @@ LLD void rj_solve_velocity(Joint& j, int ji, const LLConst& k, V2& vA, float& wA
     }
     {
         V2 Cdot = vB + cross_sv(wB, j.rB) - vA - cross_sv(wA, j.rA);
-        V2 impulse = mat22_solve(j.K11, j.K12, j.K21, j.K22, -Cdot);
+        V2 nC = -Cdot;  // b2Mat22::Solve with the loop-invariant reciprocal determinant
+        V2 impulse = mk(j.invDetK * (j.K22 * nC.x - j.K12 * nC.y), j.invDetK * (j.K11 * nC.y - j.K21 * nC.x));
         j.impulse.x += impulse.x;
         j.impulse.y += impulse.y;
         vA = vA - mA * impulse;
