@@ -433,20 +433,23 @@ LLD void cs_solve_one(VConstraint& vc, Vel& velB) {
         float vn1 = dot(dv1, normal), vn2 = dot(dv2, normal);
         V2 b = mk(vn1 - cp1.velocityBias, vn2 - cp2.velocityBias);
         b = b - mk(vc.k11 * a.x + vc.k12 * a.y, vc.k21 * a.x + vc.k22 * a.y);
-        for (;;) {
-            V2 x = -mk(vc.nm11 * b.x + vc.nm12 * b.y, vc.nm21 * b.x + vc.nm22 * b.y);
-            if (x.x >= 0.0f && x.y >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-            x.x = -cp1.normalMass * b.x; x.y = 0.0f;
-            vn2 = vc.k21 * x.x + b.y;
-            if (x.x >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-            x.x = 0.0f; x.y = -cp2.normalMass * b.y;
-            vn1 = vc.k12 * x.y + b.x;
-            if (x.y >= 0.0f && vn1 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-            x.x = 0.0f; x.y = 0.0f;
-            vn1 = b.x; vn2 = b.y;
-            if (vn1 >= 0.0f && vn2 >= 0.0f) { cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2); break; }
-            break;
-        }
+        // The four cases of the block solver, evaluated side by side and selected (the reference tries them in this
+        // order and takes the first that holds): lanes of a wave land in different cases, and the branchy form
+        // would run the impulse application once per distinct case.
+        const V2 x1 = -mk(vc.nm11 * b.x + vc.nm12 * b.y, vc.nm21 * b.x + vc.nm22 * b.y);
+        const bool ok1 = x1.x >= 0.0f && x1.y >= 0.0f;
+        const V2 x2 = mk(-cp1.normalMass * b.x, 0.0f);
+        const float vn2_2 = vc.k21 * x2.x + b.y;
+        const bool ok2 = x2.x >= 0.0f && vn2_2 >= 0.0f;
+        const V2 x3 = mk(0.0f, -cp2.normalMass * b.y);
+        const float vn1_3 = vc.k12 * x3.y + b.x;
+        const bool ok3 = x3.y >= 0.0f && vn1_3 >= 0.0f;
+        const bool ok4 = b.x >= 0.0f && b.y >= 0.0f;
+        V2 x = mk(0.0f, 0.0f);
+        x = ok3 ? x3 : x;
+        x = ok2 ? x2 : x;
+        x = ok1 ? x1 : x;
+        if (ok1 || ok2 || ok3 || ok4) cs_apply2(vc, x, a, normal, vB, wB, cp1, cp2);
     }
     velB.v = vB; velB.w = wB;
 }
@@ -1036,14 +1039,18 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
         vel.b0 = vd; vel.b1 = vd; vel.b2 = vd;  // cs_init_velocity reads slot `dyn` only
         CSolver cs;
         cs_init(cs, mem, w, k, islandSlots, nc, false, 1.0f);
+        LL_STAMP(12);
         {
             Pos pd = pos[dyn];
             toi_position(cs, pd);
             pos[dyn] = pd;
         }
+        LL_STAMP(13);
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
         cs_init_velocity(cs, w, pos, vel);
+        LL_STAMP(14);
         toi_sweeps(cs, vd);
+        LL_STAMP(15);
         {
             const float h = sub_dt;
             V2 c = pos[dyn].c; float a = pos[dyn].a;

@@ -3,11 +3,11 @@
 // Replaces the bodies of `impl Gym for LunarLanderV3` (reference src/box_2d/lunar_lander.rs: reset
 // :727-917, step :919-1167) and the box2d-rs world it drives (ll_b2.h / ll_world.h restate Box2D).
 //
-// Data layout in HBM (engine-owned SoA, column stride n_pad words; 195 state columns + 8 observation
-// columns, ~0.8 KB per env; see enum Col):
+// Data layout in HBM (engine-owned SoA, column stride n_pad words; 259 state columns + 8 observation
+// columns, ~1 KB per env of which ~0.45 KB are touched in free flight; see enum Col):
 //   3 bodies x {xf.p, sweep.c, angle, v, w, sleepTime}; 2 joints x {impulse.xy, motor, lower, upper};
 //   3 fat AABBs; terrain smooth_y[11]; prev_shaping; flag word; wind/torque indices; step/episode
-//   counters (Philox slots); 8 contact-cache slots x 16 words (loaded only when the env has contacts).
+//   counters (Philox slots); 12 contact-cache slots x 16 words (loaded only when the env has contacts).
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
 #include <math.h>
@@ -329,7 +329,8 @@ struct LunarLanderEnv final : Env {
     void launch_resets(const LLIo& io, bool all) {
         if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, list_ptr(L_RESET), (const uint32_t*)dev.work_count + L_RESET);
-        hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, list_ptr(L_RESET_SLOW), (const uint32_t*)dev.work_count + L_RESET_SLOW, 0);
+        // declined resets are rare to non-existent: a small grid (grid-stride inside) keeps the usual empty launch cheap
+        hipLaunchKernelGGL(ll_general_kernel<64>, dim3(work_grid().x < 64 ? work_grid().x : 64), dim3(64), 0, stream, dev, io, list_ptr(L_RESET_SLOW), (const uint32_t*)dev.work_count + L_RESET_SLOW, 0);
     }
     int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) override {
         if (n == 0) return MGYM_OK;

@@ -14,10 +14,12 @@ static __device__ __shared__ unsigned long long s_last;
 // hash equals the one 1..4 sweeps earlier (period p), or 180 if never.  g_cyc[kind][period 0..4][bucket of 10 sweeps]
 __device__ unsigned long long g_cyc[2][5][19];
 __device__ inline unsigned long long diag_hash(std::initializer_list<float> w) { unsigned long long h = 1469598103934665603ull; for (float f : w) { h ^= __float_as_uint(f); h *= 1099511628211ull; } return h; }
+#ifdef LL_CYCLE_DIAG  // opt-in: the hashing inflates the sweep phases
 #define LL_DIAG_SWEEP 1
 #define LL_DIAG_SWEEP_BEGIN(kind) unsigned long long dh_[4] = {1, 2, 3, 4}; int dper_ = 0, dit_ = 180; bool dok_ = true
 #define LL_DIAG_SWEEP(kind, it, ok, ...) do { dok_ = dok_ && (ok); unsigned long long h_ = diag_hash({__VA_ARGS__}); if (dper_ == 0) { for (int p_ = 0; p_ < 4; ++p_) if (h_ == dh_[p_]) { dper_ = p_ + 1; dit_ = it; break; } } dh_[3] = dh_[2]; dh_[2] = dh_[1]; dh_[1] = dh_[0]; dh_[0] = h_; } while (0)
 #define LL_DIAG_SWEEP_END(kind) do { if (dok_) atomicAdd(&g_cyc[kind][dper_][dit_ / 10], 1ull); } while (0)
+#endif
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
 #include <stdio.h>
 #include <vector>
@@ -63,12 +65,12 @@ int main(int argc, char** argv) {
     unsigned long long p[16], c[16];
     CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_prof), sizeof p)); CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cnt), sizeof c));
     const char* names[16] = {"", "collide", "island: DFS+integrate", "island: constraint init + joint init", "island: 180 sweeps", "island: integrate pos + position iters + sync",
-                             "island: sleep + fixture sync + find contacts", "solve_toi total tail", "", "toi: time_of_impact", "toi: advance+update+island build", "toi: substep solve (20 pos + 180 vel)", "", "", "", ""};
+                             "island: sleep + fixture sync + find contacts", "solve_toi total tail", "", "toi: time_of_impact", "toi: advance+update+island build", "toi: integrate + sync", "toi: cs_init", "toi: position iterations (<=20)", "toi: cs_init_velocity", "toi: velocity sweeps (<=180)"};
     double tot = 0; for (int i = 0; i < 16; ++i) tot += (double)p[i];
     printf("wave-cycles by phase over %d steps of %llu envs (general kernel only; shares, not run time):\n", steps, (unsigned long long)n);
-    for (int i = 1; i < 12; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
+    for (int i = 1; i < 16; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
     printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
-    for (int i = 1; i < 12; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
+    for (int i = 1; i < 16; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
     { unsigned long long cyc[2][5][19]; CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof cyc));
       for (int k = 0; k < 2; ++k) for (int p = 0; p < 5; ++p) { unsigned long long t = 0; for (int b = 0; b < 19; ++b) t += cyc[k][p][b]; if (!t) continue;
         printf("%s sweeps, <=2 contacts: period %d (0 = none found) n=%llu; first-detected-at histogram by 10 sweeps:", k ? "toi" : "island", p, t); for (int b = 0; b < 19; ++b) printf(" %llu", cyc[k][p][b]); printf("\n"); } }
