@@ -104,6 +104,38 @@ int main(int argc, char** argv) {
     env.reset(nullptr, nullptr, true, nullptr);
     timeit("vec4 rmode2 NT", [&](uint32_t* a) { hipLaunchKernelGGL((cartpole_step_kernel<4, 2, true>), gv, b, 0, env.stream, d, a, nullptr, rew, dn, tr); });
     env.reset(nullptr, nullptr, true, nullptr);
+    // population split into S independent sub-shards on S streams (fork/join inside one graph): the dependent-launch
+    // gap of one chain overlaps the other chain's kernel
+    for (int S : {2, 4}) {
+        if (n % (1024ull * S)) continue;
+        static hipStream_t ss[4]; static hipEvent_t ef, ej[4];
+        for (int q = 1; q < S; ++q) if (!ss[q]) CK(hipStreamCreate(&ss[q]));
+        if (!ef) { CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); for (int q = 0; q < 4; ++q) CK(hipEventCreateWithFlags(&ej[q], hipEventDisableTiming)); }
+        const uint64_t h = n / S;
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(env.stream, hipStreamCaptureModeThreadLocal));
+        CK(hipEventRecord(ef, env.stream));
+        for (int q = 1; q < S; ++q) CK(hipStreamWaitEvent(ss[q], ef, 0));
+        for (int k = 0; k < RING; ++k)
+            for (int q = 0; q < S; ++q) {
+                CartPoleDev dq = d; dq.x += q * h; dq.xd += q * h; dq.th += q * h; dq.thd += q * h; dq.ctr += q * h; dq.episode += q * h; dq.n = h; dq.env_id_base += q * h;
+                hipLaunchKernelGGL((cartpole_step_kernel<4, 2, true>), dim3((unsigned)(h / 1024)), b, 0, q ? ss[q] : env.stream, dq, act + (uint64_t)k * n + q * h, nullptr, rew + q * h, dn + q * h, tr + q * h);
+            }
+        for (int q = 1; q < S; ++q) { CK(hipEventRecord(ej[q], ss[q])); CK(hipStreamWaitEvent(env.stream, ej[q], 0)); }
+        CK(hipStreamEndCapture(env.stream, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int w = 0; w < 5; ++w) CK(hipGraphLaunch(ge, env.stream));
+        CK(hipStreamSynchronize(env.stream));
+        float tot = 0, best = 1e9;
+        for (int rnd = 0; rnd < 5; ++rnd) {
+            CK(hipEventRecord(e0, env.stream));
+            for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, env.stream));
+            CK(hipEventRecord(e1, env.stream)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= (reps * RING); tot += ms; if (ms < best) best = ms;
+        }
+        printf("vec4 rmode2 NT, %d sub-shards on %d streams  n=%llu  %.2f us/step (best %.2f)  %.0f GB/s alg  %.3e steps/s\n", S, S, (unsigned long long)n, tot / 5 * 1e3, best * 1e3, 50.0 * n / (tot / 5 * 1e-3) / 1e9, n / (tot / 5 * 1e-3));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        env.reset(nullptr, nullptr, true, nullptr);
+    }
     timeit("vec4 rmode0 + reset_done", [&](uint32_t* a) { hipLaunchKernelGGL((cartpole_step_kernel<4, 0, false>), gv, b, 0, env.stream, d, a, nullptr, rew, dn, tr);
         hipLaunchKernelGGL(cartpole_reset_kernel, gv, b, 0, env.stream, d, dn, tr, 0, 1, nullptr); });
     env.reset(nullptr, nullptr, true, nullptr);
