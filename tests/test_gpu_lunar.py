@@ -181,3 +181,25 @@ def test_lunar_lander_full_size_262144_envs():
         assert close(o[:, idx], np.concatenate([e[0] for e in exp], axis=1)).all(), f"step {t}"
         assert np.array_equal(d[idx], np.concatenate([e[2] for e in exp]))
     assert d[idx].sum() > 50   # most sampled envs have crashed by now (no resets in this test)
+
+
+def test_full_size_fast_paths_equal_the_general_path(monkeypatch):
+    """Size-independent property at BASELINE's 262 144 envs: the product launch sequence (register-only free-flight
+    kernel -> compacted general kernel -> compacted reset kernel, fused auto-reset) and the debugging mode that sends
+    every env through the general kernel (inline reset) must produce identical words for every env and step."""
+    n, steps = 1 << 18, 140
+    fast = mg.VecEnv(LL, n, seed=77, enable_wind=True, auto_reset=True)
+    monkeypatch.setenv("MGYM_LL_GENERAL_ONLY", "1")
+    slow = mg.VecEnv(LL, n, seed=77, enable_wind=True, auto_reset=True)
+    monkeypatch.delenv("MGYM_LL_GENERAL_ONLY")
+    assert np.array_equal(fast.reset(), slow.reset())
+    rng = np.random.default_rng(8)
+    finished = 0
+    for t in range(steps):
+        a = rng.integers(0, 4, n).astype(np.uint32)
+        got, exp = fast.step(a), slow.step(a)
+        for g, e, name in zip(got, exp, ("obs", "reward", "done", "truncated")):
+            assert np.array_equal(g.view(np.uint32) if g.dtype == np.float32 else g, e.view(np.uint32) if e.dtype == np.float32 else e), f"{name} at step {t}"
+        finished += int(exp[2].sum())
+    assert finished > n // 2   # most envs crashed or landed at least once, so resets and contact phases were compared
+    assert np.array_equal(fast.get_state().view(np.uint32), slow.get_state().view(np.uint32))
