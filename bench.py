@@ -322,11 +322,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "cartpole" and args.envs is None:
         # the other BASELINE configs, measured AFTER the timed region (never the headline `value`)
         extra = {}
-        for name, cnt, k in (("mountain_car", 1 << 20, 400), ("mountain_car_cont", 1 << 20, 400), ("lunar_lander", 1 << 18, 48),
+        for name, cnt, k in (("mountain_car", 1 << 20, 400), ("mountain_car_cont", 1 << 20, 400), ("lunar_lander", 1 << 18, 128),
                              ("cartpole_32Mi_envs_hbm_regime", 1 << 25, 96)):
             wl = "cartpole" if name.startswith("cartpole") else name
             st = Stepper(mg, torch, wl, cnt, local_rank, args.seed + 7, 0, stream, args.reset, args.launch)
-            st.run(RING * 2)
+            st.run(640 if wl == "lunar_lander" else RING * 2)   # LunarLander: reach the steady mix of flight / contact / resets
             st.env.sync()
             torch.cuda.synchronize()
             st.env.timer_start()
