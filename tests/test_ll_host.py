@@ -52,3 +52,20 @@ def test_device_math_header_matches_glibc():
     # 16 < |x| < 120: glibc's FMA ifunc variant may round a handful of inputs differently
     assert int(rows["sinf"]["bad_mid"]) + int(rows["cosf"]["bad_mid"]) <= 8, out
     assert int(rows["tanhf"]["bad_mid"]) == 0 and int(rows["tanhf"]["bad_large"]) == 0
+
+
+def test_kernel_source_is_clean_under_asan_and_ubsan():
+    """GPU AddressSanitizer is not available on the pool, and an out-of-bounds index in a kernel can take a GPU
+    down: run the same kernel source on the host under ASan + UBSan (contact cache, constraint tables, worklists)."""
+    ora.build()
+    odir = os.path.join(ROOT, "oracle", "_build")
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "ll_host_check_san")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=undefined", "-o", exe, os.path.join(ROOT, "tests", "native", "ll_host_check.cpp"),
+                    f"-L{odir}", "-loracle", f"-Wl,-rpath,{odir}", "-lm"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe, "128", "350", "1", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert re.search(r"mismatches=0 ", r.stdout), r.stdout[-2000:]
