@@ -970,31 +970,43 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
         float minAlpha = 1.0f;
         int order[kSlots];
         const int n_order = contact_order(w, order);
+        // b2World::SolveTOI walks the contact list once, computing the time of impact of every contact whose cached
+        // value was invalidated and tracking the minimum.  Here the walk is split into three passes with the same
+        // per-contact order and arithmetic: (1) list the contacts that need a computation, (2) compute them —
+        // lanes of a wave need different list positions, and one pass over the compacted list runs
+        // time_of_impact max-over-lanes(own count) times instead of once per list position — (3) take the minimum.
+        int need[kSlots], n_need = 0;
         for (int q = 0; q < n_order; ++q) {
-            Contact& c = w.ct[order[q]];
+            const Contact& c = w.ct[order[q]];
+            if (!c.enabled || c.toiCount > b2_maxSubSteps || c.toiFlag) continue;
+            if (!w.b[c.body].awake) continue;
+            need[n_need++] = order[q];
+        }
+        for (int j = 0; j < n_need; ++j) {
+            Contact& c = w.ct[need[j]];
+            Body& bB = w.b[c.body];
+            // put the sweeps onto the same time interval (the shared static body carries an alpha0 too)
+            float alpha0 = gA;
+            if (gA < bB.sw.alpha0) { alpha0 = bB.sw.alpha0; gA = alpha0; }
+            else if (bB.sw.alpha0 < gA) { alpha0 = gA; sweep_advance(bB.sw, alpha0); }
+            V2 ev[2];
+            edge_verts(w, c.edge, ev[0], ev[1]);
+            float beta;
+            LL_STAMP(8);
+            int state = time_of_impact(ev, tab, poly_of(c.body), bB.sw, beta);
+            LL_STAMP(9);
+            float alpha;
+            if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+            else alpha = 1.0f;
+            c.toi = alpha;
+            c.toiFlag = true;
+        }
+        for (int q = 0; q < n_order; ++q) {
+            const Contact& c = w.ct[order[q]];
             if (!c.enabled) continue;
             if (c.toiCount > b2_maxSubSteps) continue;
-            float alpha = 1.0f;
-            if (c.toiFlag) {
-                alpha = c.toi;
-            } else {
-                Body& bB = w.b[c.body];
-                if (!bB.awake) continue;
-                // put the sweeps onto the same time interval (the shared static body carries an alpha0 too)
-                float alpha0 = gA;
-                if (gA < bB.sw.alpha0) { alpha0 = bB.sw.alpha0; gA = alpha0; }
-                else if (bB.sw.alpha0 < gA) { alpha0 = gA; sweep_advance(bB.sw, alpha0); }
-                V2 ev[2];
-                edge_verts(w, c.edge, ev[0], ev[1]);
-                float beta;
-                LL_STAMP(8);
-                int state = time_of_impact(ev, tab, poly_of(c.body), bB.sw, beta);
-                LL_STAMP(9);
-                if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
-                else alpha = 1.0f;
-                c.toi = alpha;
-                c.toiFlag = true;
-            }
+            if (!c.toiFlag) continue;  // body asleep: skipped by the reference before any computation
+            const float alpha = c.toi;
             if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
         }
         if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) break;
