@@ -153,11 +153,22 @@ def cpu_baseline(workload, n, seed):
             if el > budget or steps >= 2000:
                 break
         out[label] = (n * steps / el, steps, el)
+    c1 = None
+    if workload == "cartpole":
+        # BASELINE configs[0]: CartPole-v1, ONE env, CPU step() loop (plumbing case): 1e6 steps inside the C library
+        one = ora.OracleVec(kind, 1, seed=seed)
+        one.reset()
+        t0 = time.perf_counter()
+        one.run(rng.integers(0, 2, (16, 1)).astype(np.uint32), 1_000_000)
+        c1 = (time.perf_counter() - t0) / 1e6 * 1e9
     v, steps, el = out["allcores"]
-    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    res = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{workload} {n} envs x {steps} steps (step + masked reset), {el:.1f} s, OpenMP index shards over {cores} threads; "
                       f"oracle = C restatement of the Rust reference (cargo/rustc absent: reference unbuildable)",
             "value_1core": out["1core"][0]}
+    if c1 is not None:
+        res["configs0_one_env_ns_per_step"] = c1   # step + reset-on-finish, 1 env, 1 core, 1e6 steps
+    return res
 
 
 def main():

@@ -143,6 +143,7 @@ int ora_vec_obs_dim(const ora_vec *v);
 int ora_vec_reset(ora_vec *v, const uint8_t *mask, float *obs_soa, int nthreads);
 int ora_vec_step(ora_vec *v, const void *actions, float *obs_soa, float *reward, uint8_t *done,
                  uint8_t *trunc, int nthreads);
+long ora_vec_run(ora_vec *v, const void *actions, int ring, long K, int nthreads); /* K steps + reset-on-finish */
 int ora_vec_state_cols(const ora_vec *v);
 void ora_vec_get_state(const ora_vec *v, float *soa);
 void ora_vec_set_state(ora_vec *v, const float *soa);

@@ -93,6 +93,8 @@ def lib():
         L.ora_vec_set_state.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_vec_set_dispersion.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_vec_reset_deterministic.argtypes = [C.c_void_p, C.c_void_p]
+        L.ora_vec_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int]
+        L.ora_vec_run.restype = C.c_long
         _lib = L
     return _lib
 
@@ -159,6 +161,15 @@ class OracleVec:
         if st != OK:
             raise RuntimeError(f"oracle step status {st}")
         return obs, rew, done, trunc
+
+    def run(self, actions, K, nthreads=1):
+        """K steps with reset-on-finish inside the C library (actions [ring, n], cycled); returns episodes finished."""
+        a = np.ascontiguousarray(actions, np.float32 if self.kind == MOUNTAINCAR_CONT else np.uint32)
+        assert a.ndim == 2 and a.shape[1] == self.n
+        r = lib().ora_vec_run(self._h, _ptr(a), a.shape[0], int(K), nthreads)
+        if r < 0:
+            raise RuntimeError(f"oracle run status {-r}")
+        return r
 
     @property
     def state_cols(self):

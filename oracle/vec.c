@@ -158,6 +158,40 @@ int ora_vec_reset(ora_vec *v, const uint8_t *mask, float *obs_soa, int nthreads)
     return err;
 }
 
+static int vec_step_one(ora_vec *v, long i, long n, int kind, const uint32_t *au, const float *af, float *obs_soa,
+                        float *reward, uint8_t *done, uint8_t *trunc) {
+    ora_stepinfo si = {0.0f, 0, 0};
+    int st = ORA_OK;
+    switch (kind) {
+    case 0:
+        st = ora_cartpole_step(&v->cp[i], au[i], &si);
+        if (obs_soa && st == ORA_OK)
+            for (int k = 0; k < 4; ++k) obs_soa[(size_t)k * n + i] = v->cp[i].state[k];
+        break;
+    case 1:
+        st = ora_mountaincar_step(&v->mc[i], au[i], &si);
+        if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mc[i].state[0]; obs_soa[n + i] = v->mc[i].state[1]; }
+        break;
+    case 2:
+        st = ora_mountaincar_cont_step(&v->mcc[i], af[i], &si);
+        if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mcc[i].state[0]; obs_soa[n + i] = v->mcc[i].state[1]; }
+        break;
+    case 3: {
+        float d[2], obs[8];
+        ll_dispersion(v, (size_t)i, d);
+        st = ora_lunarlander_step(v->ll[i], au[i], d, obs, &si);
+        v->ll_step[i] += 1;
+        if (obs_soa && st == ORA_OK) for (int k = 0; k < 8; ++k) obs_soa[(size_t)k * n + i] = obs[k];
+        break;
+    }
+    }
+    if (st != ORA_OK) return st;
+    if (reward) reward[i] = si.reward;
+    if (done) done[i] = si.done;
+    if (trunc) trunc[i] = si.truncated;
+    return ORA_OK;
+}
+
 int ora_vec_step(ora_vec *v, const void *actions, float *obs_soa, float *reward, uint8_t *done,
                  uint8_t *trunc, int nthreads) {
     long n = (long)v->cfg.n_envs;
@@ -165,44 +199,45 @@ int ora_vec_step(ora_vec *v, const void *actions, float *obs_soa, float *reward,
     const float *af = (const float *)actions;
     int kind = v->cfg.kind;
     int err = ORA_OK;
-    if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1)
+    if (nthreads <= 1) {  /* plain loop: no OpenMP region entry cost (it dominates a 1-env step) */
+        for (long i = 0; i < n; ++i) {
+            int st = vec_step_one(v, i, n, kind, au, af, obs_soa, reward, done, trunc);
+            if (st != ORA_OK) err = st;
+        }
+        return err;
+    }
+#pragma omp parallel for num_threads(nthreads) schedule(static)
     for (long i = 0; i < n; ++i) {
-        ora_stepinfo si = {0.0f, 0, 0};
-        int st = ORA_OK;
-        switch (kind) {
-        case 0:
-            st = ora_cartpole_step(&v->cp[i], au[i], &si);
-            if (obs_soa && st == ORA_OK)
-                for (int k = 0; k < 4; ++k) obs_soa[(size_t)k * n + i] = v->cp[i].state[k];
-            break;
-        case 1:
-            st = ora_mountaincar_step(&v->mc[i], au[i], &si);
-            if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mc[i].state[0]; obs_soa[n + i] = v->mc[i].state[1]; }
-            break;
-        case 2:
-            st = ora_mountaincar_cont_step(&v->mcc[i], af[i], &si);
-            if (obs_soa && st == ORA_OK) { obs_soa[i] = v->mcc[i].state[0]; obs_soa[n + i] = v->mcc[i].state[1]; }
-            break;
-        case 3: {
-            float d[2], obs[8];
-            ll_dispersion(v, (size_t)i, d);
-            st = ora_lunarlander_step(v->ll[i], au[i], d, obs, &si);
-            v->ll_step[i] += 1;
-            if (obs_soa && st == ORA_OK) for (int k = 0; k < 8; ++k) obs_soa[(size_t)k * n + i] = obs[k];
-            break;
-        }
-        }
+        int st = vec_step_one(v, i, n, kind, au, af, obs_soa, reward, done, trunc);
         if (st != ORA_OK) {
 #pragma omp atomic write
             err = st;
-            continue;
         }
-        if (reward) reward[i] = si.reward;
-        if (done) done[i] = si.done;
-        if (trunc) trunc[i] = si.truncated;
     }
     return err;
+}
+
+/* K steps of every env with a masked reset of finished episodes after each step (the loop a trainer runs):
+ * actions [K][n], cycled modulo `ring` rows.  Returns the number of episodes finished, or -status on error.
+ * Timing aid for BASELINE configs[0] (one env, CPU step() loop) and for the CPU baseline. */
+long ora_vec_run(ora_vec *v, const void *actions, int ring, long K, int nthreads) {
+    long n = (long)v->cfg.n_envs;
+    long finished = 0;
+    uint8_t *done = (uint8_t *)malloc((size_t)(n > 0 ? n : 1)), *trunc = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    if (!done || !trunc) { free(done); free(trunc); return -(long)ORA_BAD_CONFIG; }
+    const size_t row = (size_t)n * 4;  /* u32 and f32 actions are both 4 bytes */
+    for (long t = 0; t < K; ++t) {
+        int st = ora_vec_step(v, (const char *)actions + (size_t)(t % ring) * row, NULL, NULL, done, trunc, nthreads);
+        if (st != ORA_OK) { free(done); free(trunc); return -(long)st; }
+        int any = 0;
+        for (long i = 0; i < n; ++i) { done[i] = (uint8_t)(done[i] | trunc[i]); any |= done[i]; finished += done[i]; }
+        if (any) {
+            st = ora_vec_reset(v, done, NULL, nthreads);
+            if (st != ORA_OK) { free(done); free(trunc); return -(long)st; }
+        }
+    }
+    free(done); free(trunc);
+    return finished;
 }
 
 int ora_vec_state_cols(const ora_vec *v) {

@@ -179,3 +179,23 @@ def test_mountain_car_continuous_unpinned_semantics():
     assert rew[0] == f(0.0) - f(2.0) * f(2.0) * f(0.1)   # penalty on the un-clamped action
     assert done.tolist() == [0, 1, 0] and rew[1] == f(100.0) - f(0.1)
     assert obs[0, 2] == f(-1.2) and obs[1, 2] == 0.0
+
+
+def test_vec_run_equals_step_plus_masked_reset():
+    """ora_vec_run (the C-side K-step loop bench.py times for BASELINE configs[0]) is exactly step + reset-on-finish."""
+    import numpy as np
+    from oracle import oracle as ora
+    for kind, nact in ((ora.CARTPOLE, 2), (ora.MOUNTAINCAR, 3)):
+        a, b = ora.OracleVec(kind, 48, seed=5), ora.OracleVec(kind, 48, seed=5)
+        a.reset(), b.reset()
+        acts = np.random.default_rng(1).integers(0, nact, (16, 48)).astype(np.uint32)
+        finished = a.run(acts, 300)
+        count = 0
+        for t in range(300):
+            _, _, d, tr = b.step(acts[t % 16])
+            m = d | tr
+            count += int(m.sum())
+            if m.any():
+                b.reset(mask=m)
+        assert finished == count
+        assert np.array_equal(a.get_state().view(np.uint32), b.get_state().view(np.uint32))
