@@ -137,18 +137,17 @@ def cpu_baseline(workload, n, seed):
         n = min(n, 4096)  # LunarLander CPU sample is 4 096 envs (scaled comparison, stated in `sample`)
     cores = host_cores()
     rng = np.random.default_rng(0)
-    acts = [(rng.integers(0, nact, n).astype(np.uint32) if nact else rng.uniform(-1, 1, n).astype(np.float32))
-            for _ in range(4)]
+    acts = np.stack([(rng.integers(0, nact, n).astype(np.uint32) if nact else rng.uniform(-1, 1, n).astype(np.float32))
+                     for _ in range(4)])
     out = {}
     for label, threads, budget in (("1core", 1, 4.0), ("allcores", cores, 8.0)):
         env = ora.OracleVec(kind, n, seed=seed, **({"enable_wind": True} if workload == "lunar_lander" else {}))
         env.reset(nthreads=threads)
-        bufs = (np.zeros((env.obs_dim, n), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+        chunk = 4 if workload != "lunar_lander" else 2   # steps per call into the C loop (step + reset-on-finish)
         steps, t0 = 0, time.perf_counter()
         while True:
-            _, _, done, trunc = env.step(acts[steps % 4], nthreads=threads, out=bufs)
-            env.reset(mask=done | trunc, nthreads=threads)
-            steps += 1
+            env.run(acts, chunk, nthreads=threads)
+            steps += chunk
             el = time.perf_counter() - t0
             if el > budget or steps >= 2000:
                 break

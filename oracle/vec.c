@@ -229,8 +229,14 @@ long ora_vec_run(ora_vec *v, const void *actions, int ring, long K, int nthreads
     for (long t = 0; t < K; ++t) {
         int st = ora_vec_step(v, (const char *)actions + (size_t)(t % ring) * row, NULL, NULL, done, trunc, nthreads);
         if (st != ORA_OK) { free(done); free(trunc); return -(long)st; }
-        int any = 0;
-        for (long i = 0; i < n; ++i) { done[i] = (uint8_t)(done[i] | trunc[i]); any |= done[i]; finished += done[i]; }
+        long any = 0;
+        if (nthreads <= 1) {
+            for (long i = 0; i < n; ++i) { done[i] = (uint8_t)(done[i] | trunc[i]); any += done[i]; }
+        } else {
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : any)
+            for (long i = 0; i < n; ++i) { done[i] = (uint8_t)(done[i] | trunc[i]); any += done[i]; }
+        }
+        finished += any;
         if (any) {
             st = ora_vec_reset(v, done, NULL, nthreads);
             if (st != ORA_OK) { free(done); free(trunc); return -(long)st; }
