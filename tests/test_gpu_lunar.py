@@ -203,3 +203,31 @@ def test_full_size_fast_paths_equal_the_general_path(monkeypatch):
         finished += int(exp[2].sum())
     assert finished > n // 2   # most envs crashed or landed at least once, so resets and contact phases were compared
     assert np.array_equal(fast.get_state().view(np.uint32), slow.get_state().view(np.uint32))
+
+
+@pytest.mark.parametrize("params", [dict(gravity=-5.0, enable_wind=True, wind_power=10.0, turbulence_power=0.7),
+                                    dict(gravity=-11.9, enable_wind=False),
+                                    dict(gravity=-1.5, enable_wind=True, wind_power=20.0, turbulence_power=2.0)])
+def test_builder_parameters_against_oracle(params):
+    """LunarLanderV3::builder() parameters other than the defaults (lunar_lander.rs:278-296): gravity in (-12, 0),
+    wind and turbulence powers — fused auto-reset on, every observation word compared."""
+    n = 3072
+    env = mg.VecEnv(LL, n, seed=5, auto_reset=True, **params)
+    ref = ora.OracleVec(OLL, n, seed=5, **params)
+    assert np.array_equal(env.reset(), ref.reset(nthreads=8))
+    rng = np.random.default_rng(12)
+    finished = 0
+    for t in range(400):
+        a = rng.integers(0, 4, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a, nthreads=8)
+        assert np.array_equal(got[1].view(np.uint32), exp[1].view(np.uint32)), f"reward at step {t}"
+        assert np.array_equal(got[2], exp[2]) and not got[3].any()
+        m = exp[2]
+        if m.any():
+            finished += int(m.sum())
+            ro = ref.reset(m, nthreads=8)
+            exp_obs = np.where(m.astype(bool)[None, :], ro, exp[0])
+        else:
+            exp_obs = exp[0]
+        assert np.array_equal(got[0].view(np.uint32), exp_obs.view(np.uint32)), f"obs at step {t}"
+    assert finished > n // 4
