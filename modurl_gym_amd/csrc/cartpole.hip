@@ -43,6 +43,7 @@ struct CartPoleDev {
 
 constexpr uint32_t kStepsMask = 0x00FFFFFFu;
 constexpr int kAutoResetMode = 2;  // LDS compaction: measured 11.4 us vs 15.1 us (in place) at 1 Mi envs
+constexpr uint64_t kInPlaceResetFrom = 12ull << 20;  // envs: from here the fused reset is done in place (see step())
 constexpr bool kNtStores = true;   // non-temporal output stores: 10.9 us vs 11.4 us at 1 Mi envs
 
 struct CartPoleLane {
@@ -435,6 +436,8 @@ __global__ void cartpole_import_kernel(CartPoleDev d, const uint32_t* __restrict
 }
 
 struct CartPoleEnv final : Env {
+    // population size from which the fused reset runs in place; MGYM_CARTPOLE_INPLACE_FROM overrides (tests force either mode)
+    uint64_t inplace_from = getenv("MGYM_CARTPOLE_INPLACE_FROM") ? strtoull(getenv("MGYM_CARTPOLE_INPLACE_FROM"), nullptr, 0) : kInPlaceResetFrom;
     void* base = nullptr;
     CartPoleDev dev{};
 
@@ -502,7 +505,12 @@ struct CartPoleEnv final : Env {
                       (obs_out == nullptr || (aligned(obs_out, 16) && n % 4 == 0));
         dim3 gv(grid_for((n + 3) / 4)), gs(grid_for(n)), b(kBlock);
         if (dev.auto_reset) {
-            if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, kAutoResetMode, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+            // fused reset: LDS compaction of finished envs wins while the population is Infinity-Cache sized and up to
+            // ~8 Mi envs (77.8 vs 89.0 us at 8 Mi); past that each block makes several grid-stride passes and the
+            // compaction's barriers cost more HBM overlap than the Philox work they save (176.6 vs 211.1 us at 16 Mi,
+            // 394 vs 453 us at 32 Mi): reset in place there.  profiles/r01_cartpole_tune_variants.log
+            if (vec_ok && n >= inplace_from) hipLaunchKernelGGL((cartpole_step_kernel<4, 1, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+            else if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, kAutoResetMode, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
             else hipLaunchKernelGGL((cartpole_step_kernel<1, kAutoResetMode, kNtStores>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);
         } else {
             if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, 0, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);

@@ -428,3 +428,48 @@ def test_observation_aos_is_the_transposed_soa_view():
         aos = env.observation_aos()
         assert aos.shape == (1000, env.obs_dim) and np.array_equal(aos, obs.T)
         assert np.array_equal(env.observation(), obs)
+
+
+def test_in_place_fused_reset_mode_matches_oracle(monkeypatch):
+    """Large populations (>= 12 Mi envs) reset finished envs in place instead of through the LDS compaction; force that
+    mode at a testable size and check it against the oracle exactly like the default mode."""
+    monkeypatch.setenv("MGYM_CARTPOLE_INPLACE_FROM", "0")
+    n = 20000
+    env, ref, nact = both("cartpole", n, seed=22, auto_reset=True)
+    monkeypatch.delenv("MGYM_CARTPOLE_INPLACE_FROM")
+    env.reset(), ref.reset()
+    rng = np.random.default_rng(5)
+    finished = 0
+    for t in range(80):
+        a = rng.integers(0, nact, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a)
+        assert_same(got[1:], exp[1:], f"step {t} ")
+        finished += int((exp[2] | exp[3]).sum())
+        ref.reset(mask=exp[2] | exp[3])
+        assert np.array_equal(env.observation(), ref.get_state()[:4]), f"step {t}: post-reset obs"
+    assert finished > n
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+
+
+def test_full_size_16mi_envs_both_fused_reset_modes_agree(monkeypatch):
+    """Size-independent property in the true-HBM regime (16 777 216 envs, 0.8 GB of state + outputs): the in-place and
+    the LDS-compaction forms of the fused reset produce identical populations."""
+    n, steps = 1 << 24, 24
+    a_env = mg.VecEnv(mg.CARTPOLE, n, seed=3, auto_reset=True)            # in place (n >= 12 Mi)
+    monkeypatch.setenv("MGYM_CARTPOLE_INPLACE_FROM", str(1 << 40))
+    b_env = mg.VecEnv(mg.CARTPOLE, n, seed=3, auto_reset=True)            # LDS compaction
+    monkeypatch.delenv("MGYM_CARTPOLE_INPLACE_FROM")
+    a_env.reset_device(), b_env.reset_device()
+    rng = np.random.default_rng(2)
+    acts = [mg.DeviceArray.from_numpy(rng.integers(0, 2, n).astype(np.uint32)) for _ in range(4)]
+    outs = [[mg.DeviceArray(n, np.float32), mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)] for _ in range(2)]
+    total_done = 0
+    for t in range(steps):
+        a_env.step_device(acts[t % 4], None, *outs[0])
+        b_env.step_device(acts[t % 4], None, *outs[1])
+        a_env.sync(), b_env.sync()
+        da, db = outs[0][1].numpy(), outs[1][1].numpy()
+        assert np.array_equal(da, db) and np.array_equal(outs[0][0].numpy(), outs[1][0].numpy()), f"step {t}"
+        total_done += int(da.sum())
+    assert total_done > n // 2
+    assert np.array_equal(a_env.get_state().view(np.uint32), b_env.get_state().view(np.uint32))
