@@ -145,6 +145,8 @@ int main(int argc, char** argv) {
     timeit("vec1 rmode1", [&](uint32_t* a) { hipLaunchKernelGGL((cartpole_step_kernel<1, 1, false>), dim3(grid_for(n)), b, 0, env.stream, d, a, nullptr, rew, dn, tr); });
     env.reset(nullptr, nullptr, true, nullptr);
     }
+    timeit("pipelined persistent (inline reset)", [&](uint32_t* a) { hipLaunchKernelGGL(pipe_kernel, gv, b, 0, env.stream, d, a, rew, dn, tr); });
+    env.reset(nullptr, nullptr, true, nullptr);
     timeit("copy ceiling again (no math)", [&](uint32_t* a) { hipLaunchKernelGGL(copy_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, env.stream, d, a, rew, dn, tr); });
     env.dev.auto_reset = 0; env.reset(nullptr, nullptr, true, nullptr);
     return 0;
