@@ -218,6 +218,10 @@ def main():
         for s in steppers:
             s.run(steps)
 
+    if args.launch == "graph" and args.steps >= RING:
+        for s in steppers:
+            if s.graph is None:
+                s.build_graph()   # capture + instantiate before anything is timed, whatever the warm-up length
     run(args.warmup)
     for s in steppers:
         s.env.sync()
