@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGYM_ABI_VERSION 1
+#define MGYM_ABI_VERSION 2
 
 typedef struct mgym_env mgym_env;
 
@@ -137,6 +137,20 @@ int mgym_step(mgym_env *env, const void *actions, float *obs_out, float *reward_
 int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, float *reward_out,
                  uint8_t *done_out, uint8_t *trunc_out);
 
+/* mgym_rollout under an on-device uniform random policy (SURVEY §8f-1 "policy hook": random), so a rollout needs no
+ * [K][n] action table: env with global id g takes, at step t of this call, bit (t % 32) of word (g % 4) of
+ * Philox4x32-10(key = policy_seed; counter = (g & ~3, number of earlier mgym_rollout_uniform calls on this handle,
+ * 0x40000000 + t / 32)).  actions_out ([K][n_envs] uint32, may be NULL) receives the drawn actions.  CartPole only
+ * (Discrete(2)); n_envs and env_id_base must be multiples of 4.  Reference loop it fuses: a trainer calling
+ * `action_space().sample()` then `step()` (cartpole.rs:251-348, 350-356). */
+int mgym_rollout_uniform(mgym_env *env, uint64_t policy_seed, int32_t K, void *actions_out, float *obs_out,
+                         float *reward_out, uint8_t *done_out, uint8_t *trunc_out);
+
+/* Number of env-steps of this handle that returned done or truncated since mgym_create (StepInfo.done / .truncated,
+ * cartpole.rs:300-305): accumulated inside the step kernels by __ballot/popcount reductions of the done mask,
+ * one fire-and-forget atomic per wave.  Synchronises the stream. */
+int mgym_episode_count(mgym_env *env, uint64_t *finished);
+
 /* Zero-copy view of the engine-owned current observation, SoA with column stride *col_stride
  * floats (for CartPole/MountainCar the state columns ARE the observation — `self.state.clone()`,
  * cartpole.rs:301).  Valid until the handle is destroyed; contents follow the stream order. */
@@ -179,6 +193,11 @@ int mgym_device_count(int *count);
  * on the stream the kernels actually run on. */
 int mgym_timer_start(mgym_env *env);
 int mgym_timer_stop(mgym_env *env, float *elapsed_ms); /* synchronises */
+
+/* Test seam: evaluates, on the device, the exhaustive bit-identity checks of the cheap CartPole instruction sequences
+ * against the reference-form arithmetic (cartpole.rs:264-271 with IEEE divide and glibc-equal sin/cos); see
+ * modurl_gym_amd/csrc/selftest.hip.  mismatches[4] = {sincos, x / total_mass, n / d, whole step}; all must be 0. */
+int mgym_selftest_cartpole_math(int device, uint64_t *mismatches);
 
 /* hipGraph capture of a caller-issued launch sequence on the env's stream. */
 int mgym_graph_begin(mgym_env *env);

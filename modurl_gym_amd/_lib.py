@@ -45,6 +45,8 @@ PROTOTYPES = {
     "mgym_reset_deterministic": (C.c_int, [_vp, _vp]),
     "mgym_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgym_rollout": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "mgym_rollout_uniform": (C.c_int, [_vp, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mgym_episode_count": (C.c_int, [_vp, _u64p]),
     "mgym_observation": (C.c_int, [_vp, C.POINTER(_vp), _u64p]),
     "mgym_observation_aos": (C.c_int, [_vp, _vp]),
     "mgym_get_state": (C.c_int, [_vp, _vp]),
@@ -60,6 +62,7 @@ PROTOTYPES = {
     "mgym_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mgym_timer_start": (C.c_int, [_vp]),
     "mgym_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "mgym_selftest_cartpole_math": (C.c_int, [C.c_int, _u64p]),
     "mgym_graph_begin": (C.c_int, [_vp]),
     "mgym_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mgym_graph_launch": (C.c_int, [_vp, _vp]),
@@ -86,7 +89,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mgym_abi_version() != 1:
+    if lib.mgym_abi_version() != 2:
         raise OSError("libmgym.so ABI version mismatch")
     _lib = lib
     return lib

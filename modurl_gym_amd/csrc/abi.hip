@@ -153,6 +153,9 @@ int mgym_create(const mgym_config* cfg, mgym_env** out) {
         if (hipMalloc((void**)&impl->d_err, sizeof(uint32_t)) != hipSuccess) { st = MGYM_ERR_HIP; set_last_error("hipMalloc failed"); break; }
         if (hipHostMalloc((void**)&impl->h_err, sizeof(uint32_t), 0) != hipSuccess) { st = MGYM_ERR_HIP; set_last_error("hipHostMalloc failed"); break; }
         if (hipMemsetAsync(impl->d_err, 0, sizeof(uint32_t), impl->stream) != hipSuccess) { st = MGYM_ERR_HIP; break; }
+        if (hipMalloc((void**)&impl->d_done, kDoneShards * sizeof(unsigned long long)) != hipSuccess) { st = MGYM_ERR_HIP; set_last_error("hipMalloc failed"); break; }
+        if (hipHostMalloc((void**)&impl->h_done, kDoneShards * sizeof(unsigned long long), 0) != hipSuccess) { st = MGYM_ERR_HIP; set_last_error("hipHostMalloc failed"); break; }
+        if (hipMemsetAsync(impl->d_done, 0, kDoneShards * sizeof(unsigned long long), impl->stream) != hipSuccess) { st = MGYM_ERR_HIP; break; }
         if (hipEventCreate(&impl->ev0) != hipSuccess || hipEventCreate(&impl->ev1) != hipSuccess) { st = MGYM_ERR_HIP; break; }
         st = impl->init();
         if (st != MGYM_OK) break;
@@ -178,6 +181,8 @@ int mgym_destroy(mgym_env* env) {
         if (e->ev1) (void)hipEventDestroy(e->ev1);
         if (e->d_err) (void)hipFree(e->d_err);
         if (e->h_err) (void)hipHostFree(e->h_err);
+        if (e->d_done) (void)hipFree(e->d_done);
+        if (e->h_done) (void)hipHostFree(e->h_done);
         hipStream_t s = e->own_stream ? e->stream : nullptr;
         delete e;
         if (s) (void)hipStreamDestroy(s);
@@ -233,6 +238,25 @@ int mgym_rollout(mgym_env* env, const void* actions, int32_t K, float* obs_out, 
     if (K < 0) return bad_arg("mgym_rollout: K < 0");
     if (!actions && e->n && K) return bad_arg("mgym_rollout: actions is NULL");
     return e->rollout(actions, K, obs_out, reward_out, done_out, trunc_out);
+}
+
+int mgym_rollout_uniform(mgym_env* env, uint64_t policy_seed, int32_t K, void* actions_out, float* obs_out, float* reward_out,
+                         uint8_t* done_out, uint8_t* trunc_out) {
+    ENV_OR_FAIL(env);
+    if (K < 0) return bad_arg("mgym_rollout_uniform: K < 0");
+    if (e->cfg.env_id_base % 4 != 0) return bad_arg("mgym_rollout_uniform: env_id_base must be a multiple of 4 (policy bits are keyed per 4 consecutive global env ids)");
+    return e->rollout_uniform(policy_seed, K, actions_out, obs_out, reward_out, done_out, trunc_out);
+}
+
+int mgym_episode_count(mgym_env* env, uint64_t* finished) {
+    ENV_OR_FAIL(env);
+    if (!finished) return bad_arg("mgym_episode_count: NULL");
+    MGYM_HIP(hipMemcpyAsync(e->h_done, e->d_done, kDoneShards * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    MGYM_HIP(hipStreamSynchronize(e->stream));
+    uint64_t tot = 0;
+    for (int i = 0; i < kDoneShards; ++i) tot += e->h_done[i];
+    *finished = tot;
+    return MGYM_OK;
 }
 
 int mgym_observation(mgym_env* env, const float** obs, uint64_t* col_stride) {
@@ -308,9 +332,15 @@ int mgym_free(int device, void* ptr) {
     return MGYM_OK;
 }
 
+// The engine's kernels run on a hipStreamNonBlocking stream, which the null stream does not order against: these
+// helpers therefore return only when the copy has fully completed (hipMemcpy blocks the host; the explicit null-stream
+// synchronise covers staged pageable-memory copies), so a launch issued afterwards on any stream sees the data.
 int mgym_memcpy_h2d(int device, void* dst, const void* src, size_t bytes) {
     DeviceGuard guard(device);
-    if (bytes) MGYM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    if (bytes) {
+        MGYM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        MGYM_HIP(hipStreamSynchronize(nullptr));
+    }
     return MGYM_OK;
 }
 

@@ -5,46 +5,49 @@
 //
 // Data layout in HBM (engine-owned, one allocation, column stride n_pad words):
 //   x[n] x_dot[n] theta[n] theta_dot[n]   f32   — the state, which IS the observation (:301)
-//   ctr[n]                                u32   — bits 0..23 steps_since_reset (saturating; only
-//                                                 ">= 500" is observable, :297), bits 24..31
-//                                                 steps_beyond_terminated + 1 (0 = None, saturating)
-//   episode[n]                            u32   — resets so far: word 2 of the Philox counter
+//   ctr[n]                                u32   — steps_since_reset | steps_beyond_terminated | episode
+//                                                 (bit layout in cartpole_step.h)
 // One lane owns 4 consecutive environments: every column is read and written with one
 // 16-byte access per lane (1 KiB per wave instruction, fully coalesced); uniform constants
 // travel in SGPRs via the kernel argument block; outputs leave with non-temporal stores.
-// No MFMA: the path is element-wise.  LDS is used only by the done-mask compaction of the
-// fused auto-reset / masked reset (finished envs are rare per env but present in ~every wave).
+// No MFMA: the path is element-wise.
 //
 // Algorithmic HBM bytes per env-step (obs_out == NULL, zero-copy observation): 50
 //   state 16 R + 16 W, action 4 R, reward 4 W, done 1 W, truncated 1 W, ctr 4 R + 4 W.
-// Arithmetic follows cartpole.rs:264-283 in the written association, no contraction
-// (-ffp-contract=off), IEEE division; sin/cos from mgym_math.h (bit-identical to glibc).
+// There is no other per-env word: the episode counter that keys the reset draws rides in `ctr`.
+//
+// Arithmetic: cartpole_step.h.  A wave whose 256 environments all pass cartpole_fast_ok() (theta on the
+// small-argument path, bounded theta_dot, valid action: every live environment) runs the branch-free fast
+// form, proven bit-identical to the reference form; any other wave runs the reference form for that pass.
+//
+// Done-mask handling (fused auto-reset, MGYM_FLAG_AUTO_RESET): finished environments are rare per ENV
+// (~4.5 % per step under a random policy) but nearly every WAVE holds one, so resetting in place would make
+// every wave pay Philox4x32-10 (quarter-rate integer multiplies) four times over.  Instead each wave
+// compacts its finished envs with __ballot + popcount prefix sums into a wave-private LDS list (no block
+// barrier, no atomics), the wave's first lanes draw all new states in ONE pass, owners read theirs back.
+// The same ballots feed the per-handle finished-episode counter (mgym_episode_count).
 #include "common.h"
-#include "mgym_math.h"
+#include "cartpole_step.h"
 #include "philox.h"
 
 namespace mgym {
 
-struct CartPoleParams {
-    float gravity, masspole, total_mass, length, polemass_length, force_mag, tau;
-    float x_threshold, theta_threshold_radians;
-    int is_euler, sutton_barto;
-};
-
 struct CartPoleDev {
-    float *x, *xd, *th, *thd;
-    uint32_t *ctr, *episode;
+    float* base;        // columns x, x_dot, theta, theta_dot, ctr at base + k * n_pad (one pointer: SGPR budget)
+    uint64_t n_pad;
     uint64_t n;
     uint64_t seed, env_id_base;
     uint32_t* err;
-    CartPoleParams p;
-    int auto_reset;
+    unsigned long long* done_count;  // kDoneShards partial counts (finished env-steps)
+    __host__ __device__ float* x() const { return base; }
+    __host__ __device__ float* xd() const { return base + n_pad; }
+    __host__ __device__ float* th() const { return base + 2 * n_pad; }
+    __host__ __device__ float* thd() const { return base + 3 * n_pad; }
+    __host__ __device__ uint32_t* ctr() const { return reinterpret_cast<uint32_t*>(base + 4 * n_pad); }
 };
 
-constexpr uint32_t kStepsMask = 0x00FFFFFFu;
-constexpr int kAutoResetMode = 2;  // LDS compaction: measured 11.4 us vs 15.1 us (in place) at 1 Mi envs
-constexpr uint64_t kInPlaceResetFrom = 12ull << 20;  // envs: from here the fused reset is done in place (see step())
-constexpr bool kNtStores = true;   // non-temporal output stores: 10.9 us vs 11.4 us at 1 Mi envs
+constexpr bool kNtStores = true;   // non-temporal output stores: 10.9 us vs 11.4 us at 1 Mi envs (round 1)
+constexpr int kWaves = kBlock / 64;
 
 struct CartPoleLane {
     float x, xd, th, thd;
@@ -52,86 +55,15 @@ struct CartPoleLane {
 };
 
 // reset(): cartpole.rs:238-249 — state ~ U[-0.05, 0.05)^4 sampled in f64 then cast,
-// steps_since_reset = 0, steps_beyond_terminated = None.
-__device__ __forceinline__ void cartpole_reset_one(const CartPoleDev& d, uint64_t i, CartPoleLane& s) {
-    uint32_t ep = d.episode[i];
-    uint64_t gid = d.env_id_base + i;
-    Philox4 a = env_draw(d.seed, gid, ep, SLOT_RESET0);
-    Philox4 b = env_draw(d.seed, gid, ep, SLOT_RESET1);
-    s.x = uniform_f64_to_f32(-0.05, 0.05, a.w[0], a.w[1]);
-    s.xd = uniform_f64_to_f32(-0.05, 0.05, a.w[2], a.w[3]);
-    s.th = uniform_f64_to_f32(-0.05, 0.05, b.w[0], b.w[1]);
-    s.thd = uniform_f64_to_f32(-0.05, 0.05, b.w[2], b.w[3]);
-    s.ctr = 0u;
-    d.episode[i] = ep + 1u;
+// steps_since_reset = 0, steps_beyond_terminated = None.  `episode` = Philox counter word 2.
+__device__ __forceinline__ void cartpole_draw(uint64_t seed, uint64_t gid, uint32_t episode, float out[4]) {
+    Philox4 a = env_draw(seed, gid, episode, SLOT_RESET0);
+    Philox4 b = env_draw(seed, gid, episode, SLOT_RESET1);
+    out[0] = uniform_f64_to_f32(-0.05, 0.05, a.w[0], a.w[1]);
+    out[1] = uniform_f64_to_f32(-0.05, 0.05, a.w[2], a.w[3]);
+    out[2] = uniform_f64_to_f32(-0.05, 0.05, b.w[0], b.w[1]);
+    out[3] = uniform_f64_to_f32(-0.05, 0.05, b.w[2], b.w[3]);
 }
-
-// step(): cartpole.rs:251-348 for one environment held in registers.
-__device__ __forceinline__ void cartpole_step_one(const CartPoleParams& p, CartPoleLane& s, uint32_t action,
-                                                  float& reward, uint32_t& done, uint32_t& trunc, bool& bad) {
-    if (action >= 2u) {  // :252 assert!(action_space.contains(&action))
-        bad = true;
-        reward = 0.0f; done = 0u; trunc = 0u;
-        return;
-    }
-    float x = s.x, x_dot = s.xd, theta = s.th, theta_dot = s.thd;
-    float force = (action == 0u) ? -p.force_mag : p.force_mag;  // :258-262
-
-    float sintheta, costheta;
-    mg_sincosf(theta, &sintheta, &costheta);  // :264-265
-
-    // :267-271
-    float temp = (force + p.polemass_length * theta_dot * theta_dot * sintheta) / p.total_mass;
-    float thetaacc = (p.gravity * sintheta - costheta * temp) /
-                     (p.length * (4.0f / 3.0f - p.masspole * costheta * costheta / p.total_mass));
-    float xacc = temp - p.polemass_length * thetaacc * costheta / p.total_mass;
-
-    if (p.is_euler) {  // :273-277
-        x += p.tau * x_dot;
-        x_dot += p.tau * xacc;
-        theta += p.tau * theta_dot;
-        theta_dot += p.tau * thetaacc;
-    } else {  // :279-282 verbatim
-        x_dot += 0.5f * p.tau * (xacc + temp);
-        theta_dot += 0.5f * p.tau * (thetaacc + temp);
-        theta += p.tau * theta_dot + 0.5f * p.tau * p.tau * thetaacc;
-        theta_dot += 0.5f * p.tau * (thetaacc + temp);
-    }
-    s.x = x; s.xd = x_dot; s.th = theta; s.thd = theta_dot;  // :285-290
-
-    bool terminated = x < -p.x_threshold || x > p.x_threshold || theta < -p.theta_threshold_radians ||
-                      theta > p.theta_threshold_radians;  // :291-294
-
-    uint32_t steps = s.ctr & kStepsMask;
-    uint32_t sbt1 = s.ctr >> 24;  // steps_beyond_terminated + 1, 0 = None
-    steps = steps < kStepsMask ? steps + 1u : steps;  // :296
-
-    if (steps >= 500u) {  // :297-306 truncation takes precedence
-        sbt1 = 1u;
-        reward = 1.0f; done = 0u; trunc = 1u;
-    } else if (!terminated) {  // :310-318
-        reward = p.sutton_barto ? 0.0f : 1.0f; done = 0u; trunc = 0u;
-    } else if (sbt1 == 0u) {  // :319-329
-        sbt1 = 1u;
-        reward = p.sutton_barto ? -1.0f : 1.0f; done = 1u; trunc = 0u;
-    } else {  // :330-346
-        reward = p.sutton_barto ? -1.0f : 0.0f;
-        sbt1 = sbt1 < 255u ? sbt1 + 1u : sbt1;
-        done = 1u; trunc = 0u;
-    }
-    s.ctr = steps | (sbt1 << 24);
-}
-
-// Fused auto-reset support: finished environments are rare per ENV (a few percent per step) but
-// nearly every WAVE contains one, so resetting in place would make every wave pay two Philox
-// evaluations.  Instead the block compacts its finished envs through LDS (done-mask reduction):
-// lanes push (local env id) into a list, one pass of the block's first lanes draws the new
-// states for the compacted list, owners pick their values up again before the vector store.
-struct ResetScratch {
-    uint32_t count;
-    uint16_t idx[kBlock * 4];     // local env ids of finished envs
-    float fresh[kBlock * 4][4];   // their new states, by list slot
-};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -154,42 +86,121 @@ __device__ __forceinline__ void st1u(uint32_t* p, uint32_t a) {
     else *p = a;
 }
 
-// RMODE: how MGYM_FLAG_AUTO_RESET is realised — 0 none, 1 in place per lane, 2 LDS compaction.
-// NT: non-temporal stores for the output columns.
-template <int VEC, int RMODE, bool NT>
+// Wave-private scratch of the done-mask compaction: one wave's finished envs (at most 64 * VEC)
+template <int VEC>
+struct WaveResetScratch {
+    uint32_t ent[64 * VEC];     // (episode << 12) | local env id within the wave's 64*VEC envs
+    float fresh[64 * VEC][4];   // new states by list slot
+};
+
+// Steps the VEC environments of every lane of the wave (fast form when the whole wave qualifies), then — RESET —
+// replaces the finished ones by fresh episodes.  `wave_first` = index of the wave's first environment.
+// Returns the number of finished envs in this wave pass.  Every lane of the wave must call this (wave collectives).
+template <int VEC, bool EULER, bool SB, bool RESET>
+__device__ __forceinline__ uint32_t cartpole_wave_step(const CartPoleDev& d, CartPoleLane (&s)[VEC], const uint32_t (&a)[VEC], const bool (&valid)[VEC],
+                                                       float (&r)[VEC], uint32_t (&dn)[VEC], uint32_t (&tr)[VEC], uint64_t wave_first,
+                                                       WaveResetScratch<VEC>& lds, bool& bad) {
+    constexpr CartPoleParams P = cartpole_params(EULER ? 1 : 0, SB ? 1 : 0);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) ok = ok && cartpole_fast_ok(s[k].th, s[k].thd, a[k]);
+    if (__all(ok)) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) cartpole_step_fast<EULER, SB>(P, s[k].x, s[k].xd, s[k].th, s[k].thd, s[k].ctr, a[k], r[k], dn[k], tr[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            if (!cartpole_step_ref(P, s[k].x, s[k].xd, s[k].th, s[k].thd, s[k].ctr, a[k], r[k], dn[k], tr[k]) && valid[k]) bad = true;
+    }
+    // done-mask reduction: ballots + popcounts give every finished env its slot in the wave's list
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t slot[VEC];
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const bool fin = valid[k] && (dn[k] | tr[k]);
+        const unsigned long long m = __ballot(fin);
+        slot[k] = fin ? total + (uint32_t)__popcll(m & below) : 0xffffffffu;
+        total += (uint32_t)__popcll(m);
+    }
+    if (RESET && total) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            if (slot[k] != 0xffffffffu) lds.ent[slot[k]] = (s[k].ctr & (kCpEpMask << kCpEpShift)) | (uint32_t)(lane * VEC + k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = (uint32_t)lane; j < total; j += 64u) {  // one pass unless > 64 envs of the wave finished at once
+            const uint32_t e = lds.ent[j];
+            float f[4];
+            cartpole_draw(d.seed, d.env_id_base + wave_first + (e & 0xfffu), e >> kCpEpShift, f);
+            lds.fresh[j][0] = f[0]; lds.fresh[j][1] = f[1]; lds.fresh[j][2] = f[2]; lds.fresh[j][3] = f[3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (slot[k] != 0xffffffffu) {
+                s[k].x = lds.fresh[slot[k]][0]; s[k].xd = lds.fresh[slot[k]][1];
+                s[k].th = lds.fresh[slot[k]][2]; s[k].thd = lds.fresh[slot[k]][3];
+                s[k].ctr = cp_ctr_after_reset(s[k].ctr);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the list is reused by the wave's next pass
+    }
+    return total;
+}
+
+__device__ __forceinline__ void cartpole_flush_counts(const CartPoleDev& d, uint32_t finished, bool bad) {
+    // one fire-and-forget atomic per wave, spread over kDoneShards addresses; the (rare) error bit likewise
+    if ((threadIdx.x & 63) == 0 && finished)
+        atomicAdd(d.done_count + ((blockIdx.x * kWaves + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
+    }
+}
+
+// VEC: envs per lane (4 = 16-byte accesses; 1 = fallback for misaligned caller buffers).
+// RESET: MGYM_FLAG_AUTO_RESET.  NT: non-temporal stores for the output columns.
+template <int VEC, bool EULER, bool SB, bool RESET, bool NT>
 __global__ void __launch_bounds__(kBlock)
 cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __restrict__ obs_out,
                      float* __restrict__ rew, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ ResetScratch lds_[RMODE == 2 ? 1 : 1];
+    __shared__ WaveResetScratch<VEC> lds_[RESET ? kWaves : 1];
     constexpr uint64_t kPerBlock = (uint64_t)kBlock * VEC;
     bool bad = false;
-    // block-uniform loop (the compaction below uses block barriers)
-    for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {
+    uint32_t finished = 0;
+    WaveResetScratch<VEC>& lds = lds_[RESET ? (threadIdx.x >> 6) : 0];
+    for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {  // wave-uniform
         const uint64_t i0 = base + (uint64_t)threadIdx.x * VEC;
         CartPoleLane s[VEC];
         uint32_t a[VEC];
+        bool valid[VEC];
         float r[VEC];
         uint32_t dn[VEC], tr[VEC];
         const bool full = i0 + VEC <= d.n;
         if (VEC == 4 && full) {
             // engine columns are padded to n_pad, caller buffers were checked for 16-B alignment
-            float4 vx = *reinterpret_cast<const float4*>(d.x + i0);
-            float4 vxd = *reinterpret_cast<const float4*>(d.xd + i0);
-            float4 vth = *reinterpret_cast<const float4*>(d.th + i0);
-            float4 vthd = *reinterpret_cast<const float4*>(d.thd + i0);
-            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr + i0);
+            float4 vx = *reinterpret_cast<const float4*>(d.x() + i0);
+            float4 vxd = *reinterpret_cast<const float4*>(d.xd() + i0);
+            float4 vth = *reinterpret_cast<const float4*>(d.th() + i0);
+            float4 vthd = *reinterpret_cast<const float4*>(d.thd() + i0);
+            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr() + i0);
             uint4 va = *reinterpret_cast<const uint4*>(act + i0);
             s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x};
             s[1 % VEC] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
             s[2 % VEC] = {vx.z, vxd.z, vth.z, vthd.z, vc.z};
             s[3 % VEC] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
             a[0] = va.x; a[1 % VEC] = va.y; a[2 % VEC] = va.z; a[3 % VEC] = va.w;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) valid[k] = true;
         } else {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 uint64_t i = i0 + k;
-                if (i < d.n) {
-                    s[k] = {d.x[i], d.xd[i], d.th[i], d.thd[i], d.ctr[i]};
+                valid[k] = i < d.n;
+                if (valid[k]) {
+                    s[k] = {d.x()[i], d.xd()[i], d.th()[i], d.thd()[i], d.ctr()[i]};
                     a[k] = act[i];
                 } else {
                     s[k] = {0.f, 0.f, 0.f, 0.f, 0u};
@@ -197,51 +208,15 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) cartpole_step_one(d.p, s[k], a[k], r[k], dn[k], tr[k], bad);
-
-        if (RMODE == 1) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                if ((dn[k] | tr[k]) && (i0 + k < d.n)) cartpole_reset_one(d, i0 + k, s[k]);
-        }
-        if (RMODE == 2) {
-            ResetScratch& lds = *reinterpret_cast<ResetScratch*>(&lds_[0]);
-            if (threadIdx.x == 0) lds.count = 0;
-            __syncthreads();
-            uint32_t slot[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                slot[k] = 0xffffffffu;
-                if ((dn[k] | tr[k]) && (i0 + k < d.n)) {
-                    slot[k] = atomicAdd(&lds.count, 1u);
-                    lds.idx[slot[k]] = (uint16_t)(threadIdx.x * VEC + k);
-                }
-            }
-            __syncthreads();
-            const uint32_t cnt = lds.count;
-            for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) {
-                CartPoleLane f;
-                cartpole_reset_one(d, base + lds.idx[j], f);
-                lds.fresh[j][0] = f.x; lds.fresh[j][1] = f.xd; lds.fresh[j][2] = f.th; lds.fresh[j][3] = f.thd;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                if (slot[k] != 0xffffffffu) {
-                    s[k].x = lds.fresh[slot[k]][0]; s[k].xd = lds.fresh[slot[k]][1];
-                    s[k].th = lds.fresh[slot[k]][2]; s[k].thd = lds.fresh[slot[k]][3];
-                    s[k].ctr = 0u;
-                }
-            }
-        }
+        const uint64_t wave_first = base + (uint64_t)(threadIdx.x & ~63) * VEC;
+        finished += cartpole_wave_step<VEC, EULER, SB, RESET>(d, s, a, valid, r, dn, tr, wave_first, lds, bad);
 
         if (VEC == 4 && full) {
-            st4<NT>(d.x + i0, s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
-            st4<NT>(d.xd + i0, s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
-            st4<NT>(d.th + i0, s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
-            st4<NT>(d.thd + i0, s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
-            st4u<NT>(d.ctr + i0, s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr);
+            st4<NT>(d.x() + i0, s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
+            st4<NT>(d.xd() + i0, s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
+            st4<NT>(d.th() + i0, s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
+            st4<NT>(d.thd() + i0, s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
+            st4u<NT>(d.ctr() + i0, s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr);
             if (obs_out) {
                 *reinterpret_cast<float4*>(obs_out + i0) = make_float4(s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
                 *reinterpret_cast<float4*>(obs_out + d.n + i0) = make_float4(s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
@@ -257,8 +232,8 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 uint64_t i = i0 + k;
-                if (i < d.n) {
-                    d.x[i] = s[k].x; d.xd[i] = s[k].xd; d.th[i] = s[k].th; d.thd[i] = s[k].thd; d.ctr[i] = s[k].ctr;
+                if (valid[k]) {
+                    d.x()[i] = s[k].x; d.xd()[i] = s[k].xd; d.th()[i] = s[k].th; d.thd()[i] = s[k].thd; d.ctr()[i] = s[k].ctr;
                     if (obs_out) {
                         obs_out[i] = s[k].x; obs_out[d.n + i] = s[k].xd;
                         obs_out[2 * d.n + i] = s[k].th; obs_out[3 * d.n + i] = s[k].thd;
@@ -270,67 +245,56 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
             }
         }
     }
-    // done-mask style wave reduction of the (rare) error bit: one atomic per wave at most
-    if (__any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
-    }
+    cartpole_flush_counts(d, finished, bad);
 }
 
-// Fused K-step rollout (mgym_rollout): one lane keeps its 4 environments in registers for K steps; per step it
-// reads one 16-B action word and writes reward / done / truncated (and the observation if asked).  Identical to K
-// launches of cartpole_step_kernel<4, RMODE, NT> by construction: same per-env function, same reset compaction.
-template <int RMODE>
+// policy of a fused rollout: actions from the caller's [K][n] table, or drawn on the device
+enum { ROLL_TABLE = 0, ROLL_UNIFORM = 1 };
+
+// Fused K-step rollout (mgym_rollout / mgym_rollout_uniform): one lane keeps its 4 environments in registers for
+// K steps; per step it reads one 16-B action word (or takes the next bit of its Philox policy stream) and writes
+// reward / done / truncated (and the observation / the drawn actions if asked).  Identical to K launches of
+// cartpole_step_kernel by construction: same per-wave function.
+template <bool EULER, bool SB, bool RESET, int POLICY>
 __global__ void __launch_bounds__(kBlock)
-cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, int K, float* __restrict__ obs_out, float* __restrict__ rew,
-                        uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ ResetScratch lds_[1];
+cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_t* __restrict__ act_out, uint64_t policy_seed, uint32_t policy_call,
+                        int K, float* __restrict__ obs_out, float* __restrict__ rew, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    __shared__ WaveResetScratch<4> lds_[RESET ? kWaves : 1];
     constexpr uint64_t kPerBlock = (uint64_t)kBlock * 4;
     bool bad = false;
+    uint32_t finished = 0;
+    WaveResetScratch<4>& lds = lds_[RESET ? (threadIdx.x >> 6) : 0];
     for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {
         const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
         const bool in = i0 < d.n;  // n % 4 == 0 is required by the host wrapper
         CartPoleLane s[4];
+        bool valid[4] = {in, in, in, in};
         if (in) {
-            float4 vx = *reinterpret_cast<const float4*>(d.x + i0), vxd = *reinterpret_cast<const float4*>(d.xd + i0);
-            float4 vth = *reinterpret_cast<const float4*>(d.th + i0), vthd = *reinterpret_cast<const float4*>(d.thd + i0);
-            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr + i0);
+            float4 vx = *reinterpret_cast<const float4*>(d.x() + i0), vxd = *reinterpret_cast<const float4*>(d.xd() + i0);
+            float4 vth = *reinterpret_cast<const float4*>(d.th() + i0), vthd = *reinterpret_cast<const float4*>(d.thd() + i0);
+            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr() + i0);
             s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x}; s[1] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
             s[2] = {vx.z, vxd.z, vth.z, vthd.z, vc.z}; s[3] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
         } else {
             for (int k = 0; k < 4; ++k) s[k] = {0.f, 0.f, 0.f, 0.f, 0u};
         }
+        const uint64_t wave_first = base + (uint64_t)(threadIdx.x & ~63) * 4;
+        Philox4 bits{};  // POLICY == ROLL_UNIFORM: 128 policy bits = 32 steps of this lane's 4 envs
         for (int t = 0; t < K; ++t) {
             const uint64_t off = (uint64_t)t * d.n + i0;
             uint32_t a[4] = {0u, 0u, 0u, 0u}, dn[4], tr[4];
             float r[4];
-            if (in) { u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(act + off)); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
+            if (POLICY == ROLL_TABLE) {
+                if (in) { u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(act + off)); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
+            } else {
+                // uniform random policy: env i takes bit (t % 32) of word (i % 4) of Philox(policy_seed; lane's first
+                // global env id, policy_call, SLOT_POLICY + t / 32) — one Philox evaluation per lane per 32 steps
+                if ((t & 31) == 0) bits = env_draw(policy_seed, d.env_id_base + i0, policy_call, SLOT_POLICY + (uint32_t)(t >> 5));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cartpole_step_one(d.p, s[k], a[k], r[k], dn[k], tr[k], bad);
-            if (RMODE == 2) {  // same LDS compaction as cartpole_step_kernel
-                ResetScratch& lds = lds_[0];
-                if (threadIdx.x == 0) lds.count = 0;
-                __syncthreads();
-                uint32_t slot[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    slot[k] = 0xffffffffu;
-                    if (in && (dn[k] | tr[k])) { slot[k] = atomicAdd(&lds.count, 1u); lds.idx[slot[k]] = (uint16_t)(threadIdx.x * 4 + k); }
-                }
-                __syncthreads();
-                const uint32_t cnt = lds.count;
-                for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) {
-                    CartPoleLane f;
-                    cartpole_reset_one(d, base + lds.idx[j], f);
-                    lds.fresh[j][0] = f.x; lds.fresh[j][1] = f.xd; lds.fresh[j][2] = f.th; lds.fresh[j][3] = f.thd;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (slot[k] != 0xffffffffu) {
-                        s[k].x = lds.fresh[slot[k]][0]; s[k].xd = lds.fresh[slot[k]][1]; s[k].th = lds.fresh[slot[k]][2]; s[k].thd = lds.fresh[slot[k]][3];
-                        s[k].ctr = 0u;
-                    }
+                for (int k = 0; k < 4; ++k) a[k] = (bits.w[k] >> (t & 31)) & 1u;
+                if (in && act_out) st4u<true>(act_out + off, a[0], a[1], a[2], a[3]);
             }
+            finished += cartpole_wave_step<4, EULER, SB, RESET>(d, s, a, valid, r, dn, tr, wave_first, lds, bad);
             if (in) {
                 if (rew) st4<true>(rew + off, r[0], r[1], r[2], r[3]);
                 if (done_out) st1u<true>(reinterpret_cast<uint32_t*>(done_out + off), dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24));
@@ -343,20 +307,18 @@ cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, int K, 
             }
         }
         if (in) {
-            st4<kNtStores>(d.x + i0, s[0].x, s[1].x, s[2].x, s[3].x); st4<kNtStores>(d.xd + i0, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
-            st4<kNtStores>(d.th + i0, s[0].th, s[1].th, s[2].th, s[3].th); st4<kNtStores>(d.thd + i0, s[0].thd, s[1].thd, s[2].thd, s[3].thd);
-            st4u<kNtStores>(d.ctr + i0, s[0].ctr, s[1].ctr, s[2].ctr, s[3].ctr);
+            st4<kNtStores>(d.x() + i0, s[0].x, s[1].x, s[2].x, s[3].x); st4<kNtStores>(d.xd() + i0, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
+            st4<kNtStores>(d.th() + i0, s[0].th, s[1].th, s[2].th, s[3].th); st4<kNtStores>(d.thd() + i0, s[0].thd, s[1].thd, s[2].thd, s[3].thd);
+            st4u<kNtStores>(d.ctr() + i0, s[0].ctr, s[1].ctr, s[2].ctr, s[3].ctr);
         }
     }
-    if (__any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
-    }
+    cartpole_flush_counts(d, finished, bad);
 }
 
 // Masked reset.  One lane looks at 4 consecutive mask bytes of each mask with a single dword
-// load (2 B/env of traffic); masked envs are compacted through LDS exactly as in the fused
-// path, so one pass of the block's first lanes evaluates Philox for all of them instead of
-// every wave paying for its one or two masked lanes.  `all` skips masks and compaction.
+// load (2 B/env of traffic); masked envs are compacted through LDS, so one pass of the block's first lanes
+// evaluates Philox for all of them instead of every wave paying for its one or two masked lanes.
+// `all` skips masks and compaction.
 __global__ void __launch_bounds__(kBlock)
 cartpole_reset_kernel(CartPoleDev d, const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int all,
                       int masks_aligned, float* __restrict__ obs_out) {
@@ -395,51 +357,48 @@ cartpole_reset_kernel(CartPoleDev d, const uint8_t* __restrict__ m0, const uint8
         }
         for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) {
             const uint64_t i = base + (all ? j : (uint32_t)idx[j]);
-            CartPoleLane s;
-            cartpole_reset_one(d, i, s);
-            d.x[i] = s.x; d.xd[i] = s.xd; d.th[i] = s.th; d.thd[i] = s.thd; d.ctr[i] = s.ctr;
+            const uint32_t c = d.ctr()[i];
+            float f[4];
+            cartpole_draw(d.seed, d.env_id_base + i, c >> kCpEpShift, f);
+            d.x()[i] = f[0]; d.xd()[i] = f[1]; d.th()[i] = f[2]; d.thd()[i] = f[3]; d.ctr()[i] = cp_ctr_after_reset(c);
             if (obs_out) {
-                obs_out[i] = s.x; obs_out[d.n + i] = s.xd; obs_out[2 * d.n + i] = s.th; obs_out[3 * d.n + i] = s.thd;
+                obs_out[i] = f[0]; obs_out[d.n + i] = f[1]; obs_out[2 * d.n + i] = f[2]; obs_out[3 * d.n + i] = f[3];
             }
         }
         if (!all) __syncthreads();  // idx/count are reused by the next iteration
     }
 }
 
-// blob <-> engine columns (steps / sbt are separate blob columns)
+// blob <-> engine columns (steps / sbt / episode are separate blob columns; saturations as in cartpole_step.h)
 __global__ void cartpole_export_kernel(CartPoleDev d, uint32_t* __restrict__ blob) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
-    blob[0 * d.n + i] = as_u32(d.x[i]);
-    blob[1 * d.n + i] = as_u32(d.xd[i]);
-    blob[2 * d.n + i] = as_u32(d.th[i]);
-    blob[3 * d.n + i] = as_u32(d.thd[i]);
-    uint32_t c = d.ctr[i];
-    blob[4 * d.n + i] = c & kStepsMask;
-    blob[5 * d.n + i] = (uint32_t)((int32_t)(c >> 24) - 1);  // -1 = None
-    blob[6 * d.n + i] = d.episode[i];
+    blob[0 * d.n + i] = as_u32(d.x()[i]);
+    blob[1 * d.n + i] = as_u32(d.xd()[i]);
+    blob[2 * d.n + i] = as_u32(d.th()[i]);
+    blob[3 * d.n + i] = as_u32(d.thd()[i]);
+    uint32_t c = d.ctr()[i];
+    blob[4 * d.n + i] = c & kCpStepsMask;
+    blob[5 * d.n + i] = (uint32_t)((int32_t)((c >> kCpSbtShift) & kCpSbtMask) - 1);  // -1 = None
+    blob[6 * d.n + i] = c >> kCpEpShift;
 }
 
 __global__ void cartpole_import_kernel(CartPoleDev d, const uint32_t* __restrict__ blob) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
-    d.x[i] = as_f32(blob[0 * d.n + i]);
-    d.xd[i] = as_f32(blob[1 * d.n + i]);
-    d.th[i] = as_f32(blob[2 * d.n + i]);
-    d.thd[i] = as_f32(blob[3 * d.n + i]);
-    uint32_t steps = blob[4 * d.n + i];
-    if (steps > kStepsMask) steps = kStepsMask;
+    d.x()[i] = as_f32(blob[0 * d.n + i]);
+    d.xd()[i] = as_f32(blob[1 * d.n + i]);
+    d.th()[i] = as_f32(blob[2 * d.n + i]);
+    d.thd()[i] = as_f32(blob[3 * d.n + i]);
     int32_t sbt = (int32_t)blob[5 * d.n + i];
-    uint32_t sbt1 = sbt < 0 ? 0u : (sbt >= 254 ? 255u : (uint32_t)sbt + 1u);
-    d.ctr[i] = steps | (sbt1 << 24);
-    d.episode[i] = blob[6 * d.n + i];
+    d.ctr()[i] = cp_ctr_pack(blob[4 * d.n + i], sbt < 0 ? 0u : (uint32_t)sbt + 1u, blob[6 * d.n + i]);
 }
 
 struct CartPoleEnv final : Env {
-    // population size from which the fused reset runs in place; MGYM_CARTPOLE_INPLACE_FROM overrides (tests force either mode)
-    uint64_t inplace_from = getenv("MGYM_CARTPOLE_INPLACE_FROM") ? strtoull(getenv("MGYM_CARTPOLE_INPLACE_FROM"), nullptr, 0) : kInPlaceResetFrom;
     void* base = nullptr;
     CartPoleDev dev{};
+    bool auto_reset = false;
+    uint32_t policy_calls = 0;  // mgym_rollout_uniform calls so far (Philox counter word of the policy stream)
 
     ~CartPoleEnv() override {
         if (base) (void)hipFree(base);
@@ -448,36 +407,18 @@ struct CartPoleEnv final : Env {
     int init() override {
         obs_dim = 4;
         state_cols = 7;
-        MGYM_HIP(hipMalloc(&base, 6 * n_pad * sizeof(float)));
-        MGYM_HIP(hipMemsetAsync(base, 0, 6 * n_pad * sizeof(float), stream));
-        float* f = static_cast<float*>(base);
-        dev.x = f; dev.xd = f + n_pad; dev.th = f + 2 * n_pad; dev.thd = f + 3 * n_pad;
-        dev.ctr = reinterpret_cast<uint32_t*>(f + 4 * n_pad);
-        dev.episode = reinterpret_cast<uint32_t*>(f + 5 * n_pad);
+        MGYM_HIP(hipMalloc(&base, 5 * n_pad * sizeof(float)));
+        MGYM_HIP(hipMemsetAsync(base, 0, 5 * n_pad * sizeof(float), stream));
+        dev.base = static_cast<float*>(base);
+        dev.n_pad = n_pad;
         dev.n = n;
         dev.seed = cfg.seed;
         dev.env_id_base = cfg.env_id_base;
         dev.err = d_err;
-        dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
-        // constructor constants, cartpole.rs:45-56, f32 arithmetic in the written order
-        CartPoleParams& p = dev.p;
-        const float masscart = 1.0f;
-        p.gravity = 9.8f;
-        p.masspole = 0.1f;
-        p.total_mass = p.masspole + masscart;
-        p.length = 0.5f;
-        p.polemass_length = p.masspole * p.length;
-        p.force_mag = 10.0f;
-        p.tau = 0.02f;
-        p.theta_threshold_radians = 12.0f * 2.0f * 3.14159265358979323846f / 360.0f;
-        p.x_threshold = 2.4f;
-        p.is_euler = cfg.is_euler;
-        p.sutton_barto = cfg.sutton_barto_reward;
+        dev.done_count = d_done;
+        auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) != 0;
         // cartpole.rs:81: steps_beyond_terminated = Some(0) at construction
-        if (n) {
-            // fill ctr column with (1 << 24)
-            MGYM_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dev.ctr), 1u << 24, n, stream));
-        }
+        if (n) MGYM_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dev.ctr()), cp_ctr_pack(0u, 1u, 0u), n, stream));
         return MGYM_OK;
     }
 
@@ -493,9 +434,21 @@ struct CartPoleEnv final : Env {
     int reset_deterministic(float* obs_out) override {  // cartpole.rs:437-442: self.reset()? then state = zeros
         int st = reset(nullptr, nullptr, true, nullptr);
         if (st != MGYM_OK || n == 0) return st;
-        MGYM_HIP(hipMemsetAsync(dev.x, 0, 4 * n_pad * sizeof(float), stream));
+        MGYM_HIP(hipMemsetAsync(dev.x(), 0, 4 * n_pad * sizeof(float), stream));
         if (obs_out) MGYM_HIP(hipMemsetAsync(obs_out, 0, 4 * n * sizeof(float), stream));
         return MGYM_OK;
+    }
+
+    template <int VEC, bool RESET>
+    void launch_step(dim3 g, const uint32_t* act, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) {
+        const bool eu = cfg.is_euler, sb = cfg.sutton_barto_reward;
+        dim3 b(kBlock);
+#define MGYM_CP_LAUNCH(E, S) hipLaunchKernelGGL((cartpole_step_kernel<VEC, E, S, RESET, kNtStores>), g, b, 0, stream, dev, act, obs_out, reward, done, trunc)
+        if (eu && !sb) MGYM_CP_LAUNCH(true, false);
+        else if (eu) MGYM_CP_LAUNCH(true, true);
+        else if (!sb) MGYM_CP_LAUNCH(false, false);
+        else MGYM_CP_LAUNCH(false, true);
+#undef MGYM_CP_LAUNCH
     }
 
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
@@ -503,21 +456,29 @@ struct CartPoleEnv final : Env {
         const uint32_t* act = static_cast<const uint32_t*>(actions);
         bool vec_ok = aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) &&
                       (obs_out == nullptr || (aligned(obs_out, 16) && n % 4 == 0));
-        dim3 gv(grid_for((n + 3) / 4)), gs(grid_for(n)), b(kBlock);
-        if (dev.auto_reset) {
-            // fused reset: LDS compaction of finished envs wins while the population is Infinity-Cache sized and up to
-            // ~8 Mi envs (77.8 vs 89.0 us at 8 Mi); past that each block makes several grid-stride passes and the
-            // compaction's barriers cost more HBM overlap than the Philox work they save (176.6 vs 211.1 us at 16 Mi,
-            // 394 vs 453 us at 32 Mi): reset in place there.  profiles/r01_cartpole_tune_variants.log
-            if (vec_ok && n >= inplace_from) hipLaunchKernelGGL((cartpole_step_kernel<4, 1, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
-            else if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, kAutoResetMode, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
-            else hipLaunchKernelGGL((cartpole_step_kernel<1, kAutoResetMode, kNtStores>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+        dim3 gv(grid_for((n + 3) / 4)), gs(grid_for(n));
+        if (auto_reset) {
+            if (vec_ok) launch_step<4, true>(gv, act, obs_out, reward, done, trunc);
+            else launch_step<1, true>(gs, act, obs_out, reward, done, trunc);
         } else {
-            if (vec_ok) hipLaunchKernelGGL((cartpole_step_kernel<4, 0, kNtStores>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
-            else hipLaunchKernelGGL((cartpole_step_kernel<1, 0, kNtStores>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+            if (vec_ok) launch_step<4, false>(gv, act, obs_out, reward, done, trunc);
+            else launch_step<1, false>(gs, act, obs_out, reward, done, trunc);
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
+    }
+
+    template <int POLICY>
+    void launch_rollout(dim3 g, const uint32_t* act, uint32_t* act_out, uint64_t pseed, uint32_t pcall, int K, float* obs_out, float* reward,
+                        uint8_t* done, uint8_t* trunc) {
+        const bool eu = cfg.is_euler, sb = cfg.sutton_barto_reward, rs = auto_reset;
+        dim3 b(kBlock);
+#define MGYM_CP_ROLL(E, S, R) hipLaunchKernelGGL((cartpole_rollout_kernel<E, S, R, POLICY>), g, b, 0, stream, dev, act, act_out, pseed, pcall, K, obs_out, reward, done, trunc)
+        if (eu && !sb) { if (rs) MGYM_CP_ROLL(true, false, true); else MGYM_CP_ROLL(true, false, false); }
+        else if (eu) { if (rs) MGYM_CP_ROLL(true, true, true); else MGYM_CP_ROLL(true, true, false); }
+        else if (!sb) { if (rs) MGYM_CP_ROLL(false, false, true); else MGYM_CP_ROLL(false, false, false); }
+        else { if (rs) MGYM_CP_ROLL(false, true, true); else MGYM_CP_ROLL(false, true, false); }
+#undef MGYM_CP_ROLL
     }
 
     int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
@@ -525,15 +486,25 @@ struct CartPoleEnv final : Env {
         const uint32_t* act = static_cast<const uint32_t*>(actions);
         bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
         if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
-        dim3 gv(grid_for(n / 4)), b(kBlock);
-        if (dev.auto_reset) hipLaunchKernelGGL((cartpole_rollout_kernel<2>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
-        else hipLaunchKernelGGL((cartpole_rollout_kernel<0>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
+        launch_rollout<ROLL_TABLE>(dim3(grid_for(n / 4)), act, nullptr, 0, 0, K, obs_out, reward, done, trunc);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    int rollout_uniform(uint64_t policy_seed, int K, void* actions_out, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        uint32_t* ao = static_cast<uint32_t*>(actions_out);
+        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16)) {
+            set_last_error("mgym_rollout_uniform: n_envs must be a multiple of 4 and the buffers 16-byte aligned");
+            return MGYM_ERR_BAD_ARG;
+        }
+        launch_rollout<ROLL_UNIFORM>(dim3(grid_for(n / 4)), nullptr, ao, policy_seed, policy_calls++, K, obs_out, reward, done, trunc);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
 
     int observation(const float** obs, uint64_t* col_stride) override {
-        *obs = dev.x;
+        *obs = dev.x();
         *col_stride = n_pad;
         return MGYM_OK;
     }

@@ -17,6 +17,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kDoneShards = 256;     // per-handle finished-episode counter: partial sums, one fire-and-forget atomic per wave
 constexpr int kMaxBlocks = 8192;     // grid-stride beyond this (measured best of 2048/4096/8192/uncapped at 32 Mi envs)
 
 inline uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
@@ -43,6 +44,8 @@ struct Env {
     bool own_stream = false;
     uint32_t* d_err = nullptr;   // sticky device status word
     uint32_t* h_err = nullptr;   // pinned mirror
+    unsigned long long* d_done = nullptr;  // kDoneShards partial counts of finished env-steps (done | truncated)
+    unsigned long long* h_done = nullptr;  // pinned mirror
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     virtual ~Env() {}
@@ -58,6 +61,11 @@ struct Env {
             if (st != MGYM_OK) return st;
         }
         return MGYM_OK;
+    }
+    // K fused steps under the on-device uniform random policy (SURVEY §8f-1 policy hook)
+    virtual int rollout_uniform(uint64_t, int, void*, float*, float*, uint8_t*, uint8_t*) {
+        set_last_error("mgym_rollout_uniform: not available for this environment family");
+        return MGYM_ERR_BAD_ARG;
     }
     virtual int observation(const float** obs, uint64_t* col_stride) = 0;
     virtual int get_state(void* blob) = 0;

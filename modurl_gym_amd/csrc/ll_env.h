@@ -41,6 +41,7 @@ struct LLDev {
     const float* disp;  // dispersion override [2][n] or nullptr
     uint64_t n, n_pad, seed, env_id_base;
     uint32_t* err;
+    unsigned long long* done_count;  // kDoneShards partial counts of finished env-steps (mgym_episode_count)
     // compacted env-index lists built on the device (n words each) and their lengths (count[0..2]):
     //   0 = general steps, 1 = resets (fast path), 2 = resets the fast path declined (general path)
     uint32_t* work_list;

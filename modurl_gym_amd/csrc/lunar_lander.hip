@@ -63,6 +63,12 @@ __device__ __forceinline__ void ll_push(const LLDev& d, int which, bool want, ui
     if (want) d.work_list[(uint64_t)which * d.n_pad + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
 }
 
+// done-mask reduction for mgym_episode_count: ballot + popcount per wave pass, one fire-and-forget atomic per wave at the end
+__device__ __forceinline__ void ll_flush_done(const LLDev& d, uint32_t finished) {
+    if ((threadIdx.x & 63) == 0 && finished)
+        atomicAdd(d.done_count + ((blockIdx.x + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+}
+
 // Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
 // stepped here with the register-only fast path (ll_free.h); everything else — and every env the fast path
 // declines or that finished and must auto-reset — goes to the worklist for ll_general_kernel.
@@ -72,11 +78,12 @@ ll_free_kernel(LLDev d, LLIo io) {
     __shared__ PolyTab tab;
     stage_tab(tab, d.k);
     bool not_reset = false;
+    uint32_t finished = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // wave-uniform trip count
         const uint64_t i = base + threadIdx.x;
         const bool valid = i < d.n;
-        bool to_general = false, to_reset = false;
+        bool to_general = false, to_reset = false, is_done = false;
         if (valid) {
             const uint32_t flags = ST(C_FLAGS);
             if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
@@ -98,6 +105,7 @@ ll_free_kernel(LLDev d, LLIo io) {
                     if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
                     ll_write_obs(d, io, i, state);
                     to_reset = d.auto_reset && done;
+                    is_done = done != 0u;
                 } else {
                     to_general = true;
                 }
@@ -105,7 +113,9 @@ ll_free_kernel(LLDev d, LLIo io) {
         }
         ll_push(d, L_GENERAL, to_general, (uint32_t)i);
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
+        finished += (uint32_t)__popcll(__ballot(is_done));
     }
+    ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
 }
 
@@ -122,12 +132,13 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     bool not_reset = false, overflow = false;
+    uint32_t finished = 0;
     const uint64_t total = list ? (uint64_t)*count : d.n;
     // block-uniform trip count (the deferred-reset push below is a wave-level collective)
     for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t q = q0 + threadIdx.x;
         uint64_t i = q;
-        bool defer_reset = false;
+        bool defer_reset = false, is_done = false;
         if (q < total) {
         int mode = forced;
         if (list) { uint32_t ent = list[q]; i = ent & ~kWorkReset; mode = (ent & kWorkReset) ? 1 : 0; }
@@ -166,6 +177,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
             if (io.rew) io.rew[i] = reward;
             if (io.done_out) io.done_out[i] = (uint8_t)done;
             if (io.trunc_out) io.trunc_out[i] = 0;
+            is_done = done != 0u;
             if (!(d.auto_reset && done)) break;
             if (list) { defer_reset = true; break; }  // compacted: ll_reset_kernel draws the new episode
             need_reset = true;
@@ -176,7 +188,9 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
         }
         }
         if (list) ll_push(d, L_RESET, defer_reset, (uint32_t)i);
+        finished += (uint32_t)__popcll(__ballot(is_done));
     }
+    ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
     if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
 }
@@ -307,7 +321,7 @@ struct LunarLanderEnv final : Env {
         dev.work_count = static_cast<uint32_t*>(work_base);
         dev.work_list = static_cast<uint32_t*>(work_base) + 64;
         dev.disp = nullptr;
-        dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err;
+        dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err; dev.done_count = d_done;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
         return MGYM_OK;

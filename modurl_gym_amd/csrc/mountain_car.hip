@@ -27,9 +27,20 @@ struct MountainCarDev {
     uint32_t* episode;
     uint64_t n, seed, env_id_base;
     uint32_t* err;
+    unsigned long long* done_count;  // kDoneShards partial counts of finished env-steps (mgym_episode_count)
     MountainCarParams p;
     int auto_reset;
 };
+
+// done-mask reduction: per-lane counts of finished envs summed over the wave, one fire-and-forget atomic per wave
+__device__ __forceinline__ void mountaincar_flush_counts(const MountainCarDev& d, uint32_t finished, bool bad) {
+    for (int o = 32; o > 0; o >>= 1) finished += __shfl_down(finished, o);
+    if ((threadIdx.x & 63) == 0 && finished)
+        atomicAdd(d.done_count + ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
+    }
+}
 
 typedef float mc_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store4(float* p, float4 v) {
@@ -87,6 +98,7 @@ mountaincar_step_kernel(MountainCarDev d, const uint32_t* __restrict__ act, floa
     const uint64_t groups = (d.n + VEC - 1) / VEC;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
+    uint32_t finished = 0;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
         const uint64_t i0 = g * VEC;
         float ps[VEC], vs[VEC], r[VEC];
@@ -112,6 +124,7 @@ mountaincar_step_kernel(MountainCarDev d, const uint32_t* __restrict__ act, floa
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             mountaincar_step_one<CONT>(d.p, ps[k], vs[k], a[k], r[k], dn[k], bad);
+            finished += (dn[k] && (i0 + k < d.n)) ? 1u : 0u;
             if (d.auto_reset && dn[k] && (i0 + k < d.n)) mountaincar_reset_one(d, i0 + k, ps[k], vs[k]);
         }
         if (VEC == 4 && full) {
@@ -143,9 +156,7 @@ mountaincar_step_kernel(MountainCarDev d, const uint32_t* __restrict__ act, floa
             }
         }
     }
-    if (__any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
-    }
+    mountaincar_flush_counts(d, finished, bad);
 }
 
 // Fused K-step rollout (mgym_rollout): 4 environments per lane stay in registers for K steps; per step one 16-B
@@ -159,6 +170,7 @@ mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, i
     const uint64_t groups = d.n / 4;  // n % 4 == 0 is required by the host wrapper
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
+    uint32_t finished = 0;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
         const uint64_t i0 = g * 4;
         float4 vp = *reinterpret_cast<const float4*>(d.pos + i0), vv = *reinterpret_cast<const float4*>(d.vel + i0);
@@ -171,6 +183,7 @@ mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, i
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 mountaincar_step_one<CONT>(d.p, ps[k], vs[k], a[k], r[k], dn[k], bad);
+                finished += dn[k];
                 if (d.auto_reset && dn[k]) mountaincar_reset_one(d, i0 + k, ps[k], vs[k]);
             }
             if (rew) nt_store4(rew + off, make_float4(r[0], r[1], r[2], r[3]));
@@ -185,9 +198,7 @@ mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, i
         nt_store4(d.pos + i0, make_float4(ps[0], ps[1], ps[2], ps[3]));
         nt_store4(d.vel + i0, make_float4(vs[0], vs[1], vs[2], vs[3]));
     }
-    if (__any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
-    }
+    mountaincar_flush_counts(d, finished, bad);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -259,7 +270,7 @@ struct MountainCarEnv final : Env {
         float* f = static_cast<float*>(base);
         dev.pos = f; dev.vel = f + n_pad;
         dev.episode = reinterpret_cast<uint32_t*>(f + 2 * n_pad);
-        dev.n = n; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err;
+        dev.n = n; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err; dev.done_count = d_done;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
         MountainCarParams& p = dev.p;  // mountain_car.rs:35-40
         p.min_position = -1.2f; p.max_position = 0.6f; p.max_speed = 0.07f;

@@ -32,7 +32,8 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 
 // slots of the (env, episode) counter space
-enum : uint32_t { SLOT_RESET0 = 0, SLOT_RESET1 = 1, SLOT_RESET2 = 2, SLOT_RESET3 = 3, SLOT_STEP_BASE = 16 };
+enum : uint32_t { SLOT_RESET0 = 0, SLOT_RESET1 = 1, SLOT_RESET2 = 2, SLOT_RESET3 = 3, SLOT_STEP_BASE = 16,
+                  SLOT_POLICY = 0x40000000u /* on-device rollout policy: + step / 32, keyed by the policy seed */ };
 
 __device__ __forceinline__ Philox4 env_draw(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t slot) {
     return philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, slot,

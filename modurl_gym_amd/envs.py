@@ -172,9 +172,41 @@ class VecEnv:
         _check(self._lib.mgym_rollout(self._h, _ptr(actions), int(K), _ptr(obs_out), _ptr(reward_out), _ptr(done_out),
                                       _ptr(trunc_out)))
 
+    def rollout_uniform_device(self, policy_seed, K, actions_out=None, obs_out=None, reward_out=None, done_out=None, trunc_out=None):
+        """K fused steps under the on-device uniform random policy (mgym_rollout_uniform; CartPole)."""
+        _check(self._lib.mgym_rollout_uniform(self._h, int(policy_seed), int(K), _ptr(actions_out), _ptr(obs_out), _ptr(reward_out),
+                                              _ptr(done_out), _ptr(trunc_out)))
+
+    def rollout_uniform(self, policy_seed, K):
+        """host-array form: -> (actions [K, n], obs [K, obs_dim, n], reward [K, n], done, trunc)"""
+        n = max(self.n, 1)
+        da = DeviceArray((K, n), np.uint32, self.device)
+        do = DeviceArray((K, self.obs_dim, n), np.float32, self.device)
+        dr = DeviceArray((K, n), np.float32, self.device)
+        dd, dt = DeviceArray((K, n), np.uint8, self.device), DeviceArray((K, n), np.uint8, self.device)
+        self.rollout_uniform_device(policy_seed, K, da, do, dr, dd, dt)
+        self.sync()
+        sh = lambda x, shape: x.numpy().reshape(-1)[: int(np.prod(shape))].reshape(shape)
+        return (sh(da, (K, self.n)), sh(do, (K, self.obs_dim, self.n)), sh(dr, (K, self.n)), sh(dd, (K, self.n)), sh(dt, (K, self.n)))
+
+    def episode_count(self):
+        """env-steps of this handle that returned done or truncated since creation (mgym_episode_count; synchronises)"""
+        c = C.c_uint64()
+        _check(self._lib.mgym_episode_count(self._h, C.byref(c)))
+        return c.value
+
+    def _coerce_actions(self, actions):
+        """Discrete envs take integer actions only (reference: `action_space.contains(&action)` needs a u32 tensor,
+        cartpole.rs:252,377): floats and bools are rejected instead of being truncated; negative integers become
+        out-of-range u32 values and fail on the device like any invalid action."""
+        a = np.asarray(actions)
+        if not self.action_is_float and a.dtype.kind not in "iu":
+            raise InvalidActionError(L.ERR_INVALID_ACTION, f"discrete actions must be integers, got dtype {a.dtype}")
+        return np.ascontiguousarray(a, self.action_dtype)
+
     def rollout(self, actions):
         """K fused steps on host arrays: actions [K, n] -> (obs [K, obs_dim, n], reward [K, n], done, trunc)."""
-        a = np.ascontiguousarray(actions, self.action_dtype)
+        a = self._coerce_actions(actions)
         K = a.shape[0]
         assert a.shape == (K, self.n)
         n = max(self.n, 1)
@@ -252,7 +284,7 @@ class VecEnv:
 
     def step(self, actions):
         b = self._buffers()
-        a = np.ascontiguousarray(actions, self.action_dtype)
+        a = self._coerce_actions(actions)
         assert a.shape == (self.n,), f"actions must be [{self.n}], got {a.shape}"
         if self.n:
             b["act"].copy_from(a)
@@ -323,7 +355,7 @@ class _SingleEnv:
         a = np.asarray(action)
         if a.ndim != 0:  # cartpole.rs:392-403: a [1]-shaped action tensor is rejected (rank-0 required)
             raise InvalidActionError(L.ERR_INVALID_ACTION, f"action must be a scalar, got shape {a.shape}")
-        obs, rew, done, trunc = self.vec.step(np.array([a], self.vec.action_dtype))
+        obs, rew, done, trunc = self.vec.step(a.reshape(1))
         return StepInfo(obs[:, 0].copy(), float(rew[0]), bool(done[0]), bool(trunc[0]))
 
     def observation_space(self):

@@ -31,6 +31,23 @@
 #define b2_maxFloat FLT_MAX
 
 /* ------------------------------------------------------------------------- b2_math.h */
+/* Optional work statistics of the contact path (tools/ll_work_stats.c builds this file with -DORA_STATS);
+ * never compiled into liboracle.so. */
+#ifdef ORA_STATS
+typedef struct {
+    long steps, steps_with_contacts;
+    long hist_contacts[16], hist_touching[16], hist_pos_iters[64];
+    long toi_calls, toi_outer_iters, toi_root_iters, toi_pushback, gjk_calls, gjk_iters;
+    long hist_toi_calls[64], hist_substeps[32], hist_rejected[32];
+    long toi_island_contacts[16], toi_pos_iters;
+    int cur_toi_calls, cur_substeps, cur_rejected;
+} ora_b2_stats;
+ora_b2_stats g_b2_stats;
+#define STAT(x) do { x; } while (0)
+#else
+#define STAT(x) do { } while (0)
+#endif
+
 static b2v V(float x, float y) { b2v r = {x, y}; return r; }
 static b2v vadd(b2v a, b2v b) { return V(a.x + b.x, a.y + b.y); }
 static b2v vsub(b2v a, b2v b) { return V(a.x - b.x, a.y - b.y); }
@@ -1161,7 +1178,10 @@ static void solve_island(b2world *w, float dt, float inv_dt, float dtRatio, int 
     }
 
     int positionSolved = 0;
+    STAT(g_b2_stats.hist_touching[nc < 15 ? nc : 15]++);
+    int stat_pos_iters = 0; (void)stat_pos_iters;
     for (int it = 0; it < posIters; ++it) {
+        STAT(stat_pos_iters++);
         int contactsOkay = cs_solve_position(s, 0, 0, 0);
         int jointsOkay = 1;
         for (int j = 0; j < nj; ++j) {
@@ -1171,6 +1191,7 @@ static void solve_island(b2world *w, float dt, float inv_dt, float dtRatio, int 
         if (contactsOkay && jointsOkay) { positionSolved = 1; break; }
     }
 
+    STAT(if (nc > 0) g_b2_stats.hist_pos_iters[stat_pos_iters < 63 ? stat_pos_iters : 63]++);
     for (int i = 0; i < nb; ++i) {
         b2body *b = &w->bodies[islandBodies[i]];
         b->sw.c = positions[i].c; b->sw.a = positions[i].a;
@@ -1455,7 +1476,9 @@ static int time_of_impact(const dproxy *proxyA, const dproxy *proxyB, b2sweep sw
     int iter = 0;
     scache cache;
     cache.count = 0; cache.metric = 0.0f;
+    STAT(g_b2_stats.toi_calls++; g_b2_stats.cur_toi_calls++);
     for (;;) {
+        STAT(g_b2_stats.toi_outer_iters++);
         b2xf xfA = sweep_xf(&sweepA, t1), xfB = sweep_xf(&sweepB, t1);
         float distance = gjk_distance(&cache, proxyA, xfA, proxyB, xfB);
         if (distance <= 0.0f) { state = TOI_OVERLAPPED; *t_out = 0.0f; break; }
@@ -1480,12 +1503,14 @@ static int time_of_impact(const dproxy *proxyA, const dproxy *proxyB, b2sweep sw
                 if (rootIterCount & 1) t = a1 + (target - s1) * (a2 - a1) / (s2 - s1);
                 else t = 0.5f * (a1 + a2);
                 ++rootIterCount;
+                STAT(g_b2_stats.toi_root_iters++);
                 float s = sep_evaluate(&fcn, indexA, indexB, t);
                 if (fabs1(s - target) < tolerance) { t2 = t; break; }
                 if (s > target) { a1 = t; s1 = s; } else { a2 = t; s2 = s; }
                 if (rootIterCount == 50) break;
             }
             ++pushBackIter;
+            STAT(g_b2_stats.toi_pushback++);
             if (pushBackIter == B2_MAX_POLY) break;
         }
         ++iter;
@@ -1553,6 +1578,7 @@ static void solve_toi(b2world *w, float dt, int velIters) {
         minContact->toiFlag = 0;
         ++minContact->toiCount;
         if (!minContact->enabled || !minContact->touching) {
+            STAT(g_b2_stats.cur_rejected++);
             minContact->enabled = 0;
             bA->sw = backup1; bB->sw = backup2;
             body_sync_transform(bA); body_sync_transform(bB);
@@ -1588,7 +1614,9 @@ static void solve_toi(b2world *w, float dt, int velIters) {
         csolver cs2;
         csolver *s = &cs2;
         cs_init(s, w, islandContacts, nc, positions, velocities, islandIndex, 0, 1.0f);
+        STAT(g_b2_stats.cur_substeps++; g_b2_stats.toi_island_contacts[nc < 15 ? nc : 15]++);
         for (int i = 0; i < 20; ++i) {
+            STAT(g_b2_stats.toi_pos_iters++);
             int contactsOkay = cs_solve_position(s, 1, 0, 1);
             if (contactsOkay) break;
         }
@@ -1754,9 +1782,24 @@ void b2w_step(b2world *w, float dt, int velIters, int posIters) {
     if (w->newContacts) { find_new_contacts(w); w->newContacts = 0; }
     float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
     float dtRatio = w->inv_dt0 * dt;
+#ifdef ORA_STATS
+    int stat_nc = 0;
+    for (int i = 0; i < B2_N_CONTACTS; ++i) stat_nc += w->contacts[i].exists ? 1 : 0;
+    g_b2_stats.steps++;
+    g_b2_stats.cur_toi_calls = g_b2_stats.cur_substeps = g_b2_stats.cur_rejected = 0;
+#endif
     collide(w);
     if (dt > 0.0f) solve_island(w, dt, inv_dt, dtRatio, velIters, posIters);
     if (dt > 0.0f) solve_toi(w, dt, velIters);
     if (dt > 0.0f) w->inv_dt0 = inv_dt;
+#ifdef ORA_STATS
+    if (stat_nc > 0) {
+        g_b2_stats.steps_with_contacts++;
+        g_b2_stats.hist_contacts[stat_nc < 15 ? stat_nc : 15]++;
+        g_b2_stats.hist_toi_calls[g_b2_stats.cur_toi_calls < 63 ? g_b2_stats.cur_toi_calls : 63]++;
+        g_b2_stats.hist_substeps[g_b2_stats.cur_substeps < 31 ? g_b2_stats.cur_substeps : 31]++;
+        g_b2_stats.hist_rejected[g_b2_stats.cur_rejected < 31 ? g_b2_stats.cur_rejected : 31]++;
+    }
+#endif
     for (int b = 1; b <= w->n_dyn; ++b) { w->bodies[b].force = V(0.0f, 0.0f); w->bodies[b].torque = 0.0f; } /* ClearForces */
 }

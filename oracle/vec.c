@@ -7,7 +7,8 @@
  * shard of that loop (used for the "all host cores" CPU baseline).
  *
  * State blob layout ([col][n] 4-byte words; integer columns are bit patterns):
- *   cartpole        : x, x_dot, theta, theta_dot, steps_since_reset(u32), sbt(i32, -1=None), episode(u32)
+ *   cartpole        : x, x_dot, theta, theta_dot, steps_since_reset(u32, saturating at 1023), sbt(i32, -1=None, saturating at 2),
+ *                     episode(u32 mod 2^20)
  *   mountaincar(+c) : position, velocity, episode(u32)
  *   lunarlander     : ora_lunarlander_state_floats() columns (see lunar_lander.c) + episode(u32)
  */
@@ -82,7 +83,9 @@ int ora_vec_obs_dim(const ora_vec *v) {
 
 static void draw(const ora_vec *v, size_t i, uint32_t slot, uint32_t w[4]) {
     uint64_t id = v->cfg.env_id_base + (uint64_t)i;
-    uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), v->episode[i], slot};
+    /* CartPole keeps its episode counter in 20 bits of the per-env counter word (modurl_gym_amd/csrc/cartpole_step.h) */
+    uint32_t ep = v->cfg.kind == 0 ? (v->episode[i] & 0xFFFFFu) : v->episode[i];
+    uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), ep, slot};
     uint32_t key[2] = {(uint32_t)v->cfg.seed, (uint32_t)(v->cfg.seed >> 32)};
     ora_philox4x32_10(ctr, key, w);
 }
@@ -261,11 +264,13 @@ void ora_vec_get_state(const ora_vec *v, float *soa) {
         case 0: {
             const ora_cartpole *e = &v->cp[i];
             for (int k = 0; k < 4; ++k) soa[(size_t)k * n + i] = e->state[k];
-            uint64_t s = e->steps_since_reset > 0xFFFFFFu ? 0xFFFFFFu : e->steps_since_reset;
+            /* the engine's counter word saturates: steps at 1023 (only ">= 500" is observable), sbt at Some(2)
+             * (only None/Some is observable), episode wraps at 2^20 */
+            uint64_t s = e->steps_since_reset > 1023u ? 1023u : e->steps_since_reset;
             soa[4 * n + i] = u2f((uint32_t)s);
-            int32_t sbt = e->sbt_is_some ? (int32_t)(e->sbt > 254 ? 254 : e->sbt) : -1;
+            int32_t sbt = e->sbt_is_some ? (int32_t)(e->sbt > 2 ? 2 : e->sbt) : -1;
             soa[5 * n + i] = u2f((uint32_t)sbt);
-            soa[6 * n + i] = u2f(v->episode[i]);
+            soa[6 * n + i] = u2f(v->episode[i] & 0xFFFFFu);
             break;
         }
         case 1:

@@ -7,7 +7,7 @@ pub struct mgym_env {
     _opaque: [u8; 0],
 }
 
-pub const MGYM_ABI_VERSION: c_int = 1;
+pub const MGYM_ABI_VERSION: c_int = 2;
 
 pub const MGYM_OK: c_int = 0;
 pub const MGYM_ERR_INVALID_ACTION: c_int = 1;
@@ -84,6 +84,18 @@ unsafe extern "C" {
         done_out: *mut u8,
         trunc_out: *mut u8,
     ) -> c_int;
+    pub fn mgym_rollout_uniform(
+        env: *mut mgym_env,
+        policy_seed: u64,
+        k: i32,
+        actions_out: *mut c_void,
+        obs_out: *mut f32,
+        reward_out: *mut f32,
+        done_out: *mut u8,
+        trunc_out: *mut u8,
+    ) -> c_int;
+    pub fn mgym_episode_count(env: *mut mgym_env, finished: *mut u64) -> c_int;
+    pub fn mgym_selftest_cartpole_math(device: c_int, mismatches: *mut u64) -> c_int;
     pub fn mgym_observation(env: *mut mgym_env, obs: *mut *const f32, col_stride: *mut u64) -> c_int;
     pub fn mgym_observation_aos(env: *mut mgym_env, out_aos: *mut f32) -> c_int;
     pub fn mgym_get_state(env: *mut mgym_env, blob: *mut c_void) -> c_int;

@@ -430,46 +430,151 @@ def test_observation_aos_is_the_transposed_soa_view():
         assert np.array_equal(env.observation(), obs)
 
 
-def test_in_place_fused_reset_mode_matches_oracle(monkeypatch):
-    """Large populations (>= 12 Mi envs) reset finished envs in place instead of through the LDS compaction; force that
-    mode at a testable size and check it against the oracle exactly like the default mode."""
-    monkeypatch.setenv("MGYM_CARTPOLE_INPLACE_FROM", "0")
-    n = 20000
+def test_many_envs_of_one_wave_finish_at_once():
+    """The fused auto-reset compacts a wave's finished envs into a 64-wide list pass by pass: force whole waves (256
+    envs) to finish in the same step (list longer than one pass) next to waves with none, against the oracle."""
+    n = 4096
     env, ref, nact = both("cartpole", n, seed=22, auto_reset=True)
-    monkeypatch.delenv("MGYM_CARTPOLE_INPLACE_FROM")
     env.reset(), ref.reset()
+    s = ref.get_state()
+    s[0, 256:1024] = 3.0          # envs 256..1023: beyond x_threshold -> three full waves finish at once
+    s[0, 2048:2048 + 70] = -3.0   # 70 consecutive envs of one wave (two passes), the rest of it alive
+    s[4, 3000:3100] = np.array([499] * 100, np.uint32).view(np.float32)  # truncations
+    ref.set_state(s), env.set_state(s)
     rng = np.random.default_rng(5)
-    finished = 0
-    for t in range(80):
+    for t in range(3):
         a = rng.integers(0, nact, n).astype(np.uint32)
         got, exp = env.step(a), ref.step(a)
         assert_same(got[1:], exp[1:], f"step {t} ")
-        finished += int((exp[2] | exp[3]).sum())
+        if t == 0:
+            assert exp[2][256:1024].all() and exp[3][3000:3100].all()
         ref.reset(mask=exp[2] | exp[3])
         assert np.array_equal(env.observation(), ref.get_state()[:4]), f"step {t}: post-reset obs"
-    assert finished > n
     assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
 
 
-def test_full_size_16mi_envs_both_fused_reset_modes_agree(monkeypatch):
-    """Size-independent property in the true-HBM regime (16 777 216 envs, 0.8 GB of state + outputs): the in-place and
-    the LDS-compaction forms of the fused reset produce identical populations."""
-    n, steps = 1 << 24, 24
-    a_env = mg.VecEnv(mg.CARTPOLE, n, seed=3, auto_reset=True)            # in place (n >= 12 Mi)
-    monkeypatch.setenv("MGYM_CARTPOLE_INPLACE_FROM", str(1 << 40))
-    b_env = mg.VecEnv(mg.CARTPOLE, n, seed=3, auto_reset=True)            # LDS compaction
-    monkeypatch.delenv("MGYM_CARTPOLE_INPLACE_FROM")
-    a_env.reset_device(), b_env.reset_device()
+def test_bench_variant_1mi_envs_graph_replay_fused_reset_vs_oracle():
+    """Exactly what bench.py times (BASELINE configs[1]): 1 048 576 envs, MGYM_FLAG_AUTO_RESET, hipGraph of 16 step
+    launches, obs_out = NULL, action ring of 16 columns — 32 steps (two replays) against the oracle: reward / done /
+    truncated of the last step of each replay and the full state blob afterwards, bit for bit."""
+    n, ring = 1 << 20, 16
+    env, ref, _ = both("cartpole", n, seed=0x5EED0001, auto_reset=True)
+    env.reset_device(), ref.reset(nthreads=8)
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 2, (ring, n)).astype(np.uint32)
+    d_act = [mg.DeviceArray.from_numpy(acts[k]) for k in range(ring)]
+    rew, done, trunc = mg.DeviceArray(n, np.float32), mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)
+    g = env.graph_capture(lambda: [env.step_device(d_act[k], None, rew, done, trunc) for k in range(ring)])
+    finished = 0
+    for rep in range(2):
+        env.graph_launch(g)
+        env.sync()
+        for k in range(ring):
+            exp = ref.step(acts[k], nthreads=8)
+            m = exp[2] | exp[3]
+            finished += int(m.sum())
+            ref.reset(mask=m, nthreads=8)
+        assert np.array_equal(rew.numpy(), exp[1]) and np.array_equal(done.numpy(), exp[2]) and np.array_equal(trunc.numpy(), exp[3]), f"replay {rep}"
+        assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32)), f"replay {rep}: state blob"
+    env.graph_destroy(g)
+    assert finished > n                      # every env restarted more than once on average
+    assert env.episode_count() == finished   # the kernels' ballot/popcount reduction of the done mask
+
+
+def test_full_size_16mi_envs_true_hbm_regime_vs_oracle():
+    """16 777 216 envs (0.8 GB of state + outputs: beyond the 256 MiB Infinity Cache), fused auto-reset, 12 steps
+    against the oracle bit for bit (state blob, reward, flags), plus the finished-episode count."""
+    n, steps = 1 << 24, 12
+    env, ref, _ = both("cartpole", n, seed=3, auto_reset=True)
+    env.reset_device(), ref.reset(nthreads=16)
     rng = np.random.default_rng(2)
-    acts = [mg.DeviceArray.from_numpy(rng.integers(0, 2, n).astype(np.uint32)) for _ in range(4)]
-    outs = [[mg.DeviceArray(n, np.float32), mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)] for _ in range(2)]
-    total_done = 0
+    acts = [rng.integers(0, 2, n).astype(np.uint32) for _ in range(4)]
+    d_act = [mg.DeviceArray.from_numpy(a) for a in acts]
+    rew, done, trunc = mg.DeviceArray(n, np.float32), mg.DeviceArray(n, np.uint8), mg.DeviceArray(n, np.uint8)
+    total = 0
     for t in range(steps):
-        a_env.step_device(acts[t % 4], None, *outs[0])
-        b_env.step_device(acts[t % 4], None, *outs[1])
-        a_env.sync(), b_env.sync()
-        da, db = outs[0][1].numpy(), outs[1][1].numpy()
-        assert np.array_equal(da, db) and np.array_equal(outs[0][0].numpy(), outs[1][0].numpy()), f"step {t}"
-        total_done += int(da.sum())
-    assert total_done > n // 2
-    assert np.array_equal(a_env.get_state().view(np.uint32), b_env.get_state().view(np.uint32))
+        env.step_device(d_act[t % 4], None, rew, done, trunc)
+        env.sync()
+        exp = ref.step(acts[t % 4], nthreads=16)
+        assert np.array_equal(done.numpy(), exp[2]) and np.array_equal(rew.numpy(), exp[1]) and np.array_equal(trunc.numpy(), exp[3]), f"step {t}"
+        m = exp[2] | exp[3]
+        total += int(m.sum())
+        ref.reset(mask=m, nthreads=16)
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+    assert total > 0 and env.episode_count() == total
+
+
+def test_cartpole_fast_math_exhaustive_on_gpu():
+    """mgym_selftest_cartpole_math: the exhaustive bit-identity enumerations of tests/native/cartpole_fast_check.cpp,
+    evaluated by gfx950 kernels (hardware v_rcp_f32 / fused multiply-add / IEEE divide): all four counts must be 0."""
+    import ctypes as C
+    from modurl_gym_amd import _lib
+    out = (C.c_uint64 * 4)()
+    assert _lib.load().mgym_selftest_cartpole_math(0, out) == _lib.OK
+    assert list(out) == [0, 0, 0, 0], f"mismatches (sincos, x/M, n/d, step) = {list(out)}"
+
+
+def test_episode_count_counts_finished_env_steps():
+    for name in ("cartpole", "mountain_car"):
+        n = 5000
+        env, ref, nact = both(name, n, seed=9)           # no auto-reset: finished envs keep reporting done
+        env.reset(), ref.reset()
+        if name == "mountain_car":
+            s = ref.get_state(); s[0] = 0.48; s[1] = 0.03; ref.set_state(s); env.set_state(s)
+        rng = np.random.default_rng(1)
+        total = 0
+        for t in range(40):
+            a = rng.integers(0, nact, n).astype(np.uint32)
+            got, exp = env.step(a), ref.step(a)
+            assert_same(got, exp, f"{name} step {t} ")
+            total += int((exp[2] | exp[3]).sum())
+        assert total > 0 and env.episode_count() == total, name
+
+
+def policy_actions(policy_seed, call, K, n, base=0):
+    """The documented on-device uniform policy of mgym_rollout_uniform, restated with the oracle's Philox."""
+    out = np.zeros((K, n), np.uint32)
+    for g0 in range(0, n, 4):
+        gid = base + g0
+        for blk in range((K + 31) // 32):
+            w = ora.philox([gid & 0xFFFFFFFF, gid >> 32, call, 0x40000000 + blk], [policy_seed & 0xFFFFFFFF, policy_seed >> 32])
+            for t in range(blk * 32, min(K, blk * 32 + 32)):
+                for k in range(min(4, n - g0)):
+                    out[t, g0 + k] = (w[k] >> (t & 31)) & 1
+    return out
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_rollout_uniform_policy_equals_oracle_driven_by_the_same_bits(auto_reset):
+    n, K, base = 2048, 70, 4096
+    env = mg.VecEnv(mg.CARTPOLE, n, seed=17, env_id_base=base, auto_reset=auto_reset)
+    ref = ora.OracleVec(ora.CARTPOLE, n, seed=17, env_id_base=base)
+    env.reset(), ref.reset()
+    for call in range(2):
+        acts, obs, rew, done, trunc = env.rollout_uniform(0xABCDEF12345, K)
+        exp_a = policy_actions(0xABCDEF12345, call, K, n, base)
+        assert np.array_equal(acts, exp_a), f"call {call}: drawn actions"
+        assert 0.45 < acts.mean() < 0.55
+        for t in range(K):
+            eo, er, ed, et = ref.step(exp_a[t])
+            assert np.array_equal(rew[t], er) and np.array_equal(done[t], ed) and np.array_equal(trunc[t], et), f"call {call} step {t}"
+            if auto_reset:
+                ref.reset(mask=ed | et)
+                assert np.array_equal(obs[t], ref.get_state()[:4])
+            else:
+                assert np.array_equal(obs[t], eo)
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+    with pytest.raises(mg.MgymError):
+        mg.VecEnv(mg.CARTPOLE, 8, env_id_base=2).rollout_uniform(1, 4)   # env_id_base must be a multiple of 4
+    with pytest.raises(mg.MgymError):
+        mg.VecEnv(mg.MOUNTAINCAR, 8).rollout_uniform(1, 4)               # CartPole only
+
+
+def test_discrete_actions_must_be_integers():
+    env = mg.VecEnv(mg.CARTPOLE, 4)
+    env.reset()
+    with pytest.raises(mg.InvalidActionError):
+        env.step(np.array([0.0, 1.9, 1.0, 0.0], np.float32))   # would silently truncate to 1
+    with pytest.raises(mg.InvalidActionError):
+        env.step(np.array([True, False, True, False]))
+    env.step(np.array([0, 1, 1, 0], np.int64))                 # any integer dtype is fine
