@@ -72,8 +72,11 @@ class Stepper:
         self.reward = torch.empty(n, device=f"cuda:{device}", dtype=torch.float32)
         self.done = torch.zeros(n, device=f"cuda:{device}", dtype=torch.uint8)
         self.trunc = torch.zeros(n, device=f"cuda:{device}", dtype=torch.uint8)
+        # the tensors above were filled on torch's current stream; the engine launches on `stream`: order them
+        stream.wait_stream(torch.cuda.current_stream(device))
         self.env.reset_device(None, None)
         self.graph = None
+        self.tail_graphs = {}
         self.t = 0
 
     def one(self, k):
@@ -83,23 +86,33 @@ class Stepper:
         if self.reset_mode == "separate":
             self.env.reset_done_device(self.done, self.trunc, None)
 
-    def build_graph(self):
-        self.graph = self.env.graph_capture(lambda: [self.one(k) for k in range(RING)])
+    def build_graph(self, steps=None):
+        """Capture + instantiate, before anything is timed, the graphs that `run(steps)` will replay: one of RING step
+        launches and — when `steps` is not a multiple of RING — one of exactly the remainder, so a timed region of K
+        steps is graph replays only (the same K step launches, no eager tail) however small K is."""
+        if self.graph is None:
+            self.graph = self.env.graph_capture(lambda: [self.one(k) for k in range(RING)])
+        rem = (steps or 0) % RING
+        if rem and rem not in self.tail_graphs:
+            self.tail_graphs[rem] = self.env.graph_capture(lambda: [self.one(k) for k in range(rem)])
 
     def run(self, steps):
-        """issue exactly `steps` steps on the stream (graph replays of RING steps + eager remainder)"""
-        if self.launch == "graph" and self.graph is None and steps >= RING:
-            self.build_graph()
-        full = steps // RING if self.graph is not None else 0
-        for _ in range(full):
+        """issue exactly `steps` steps on the stream"""
+        if self.launch != "graph":
+            for k in range(steps):
+                self.one(self.t + k)
+            self.t += steps
+            return
+        self.build_graph(steps)   # no-op when the graphs exist already (they do for the timed region)
+        for _ in range(steps // RING):
             self.env.graph_launch(self.graph)
-        for k in range(steps - full * RING):
-            self.one(self.t + k)
-        self.t += steps - full * RING
+        if steps % RING:
+            self.env.graph_launch(self.tail_graphs[steps % RING])
 
     def close(self):
-        if self.graph is not None:
-            self.env.graph_destroy(self.graph)
+        for g in [self.graph] + list(self.tail_graphs.values()):
+            if g is not None:
+                self.env.graph_destroy(g)
         self.env.close()
 
 
@@ -121,7 +134,9 @@ def host_cores():
                     c = min(c, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
         except Exception:
             pass
-    return max(1, min(c, int(os.environ.get("MGYM_BENCH_CORES", "16"))))  # a 1-GPU box has a 16-CPU share
+    if os.environ.get("MGYM_BENCH_CORES"):   # explicit override; otherwise what affinity + cgroup quota allow
+        c = min(c, int(os.environ["MGYM_BENCH_CORES"]))
+    return max(1, min(c, 64))   # `cores` reports the threads actually used; 64 bounds the OpenMP team on a big shared host
 
 
 def cpu_baseline(workload, n, seed):
@@ -218,10 +233,10 @@ def main():
         for s in steppers:
             s.run(steps)
 
-    if args.launch == "graph" and args.steps >= RING:
+    if args.launch == "graph":
         for s in steppers:
-            if s.graph is None:
-                s.build_graph()   # capture + instantiate before anything is timed, whatever the warm-up length
+            s.build_graph(args.steps)   # capture + instantiate before anything is timed, whatever the warm-up length
+            s.build_graph(args.warmup)
     run(args.warmup)
     for s in steppers:
         s.env.sync()

@@ -160,6 +160,16 @@ __device__ __forceinline__ void cartpole_flush_counts(const CartPoleDev& d, uint
     }
 }
 
+// 16-byte access at (uniform base pointer) + (32-bit per-lane byte offset): lowers to global_load/store with the
+// base in SGPRs and the lane offset in one VGPR (no 64-bit per-lane address arithmetic, which was ~90 VALU
+// instructions per wave pass when every column address was formed per lane)
+template <typename T> __device__ __forceinline__ const T* at(const void* base, uint32_t byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ T* at(void* base, uint32_t byte_off) {
+    return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
+
 // VEC: envs per lane (4 = 16-byte accesses; 1 = fallback for misaligned caller buffers).
 // RESET: MGYM_FLAG_AUTO_RESET.  NT: non-temporal stores for the output columns.
 template <int VEC, bool EULER, bool SB, bool RESET, bool NT>
@@ -171,77 +181,77 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
     bool bad = false;
     uint32_t finished = 0;
     WaveResetScratch<VEC>& lds = lds_[RESET ? (threadIdx.x >> 6) : 0];
+    const uint32_t lane_env = threadIdx.x * VEC;     // first env of this lane within the block's slice
+    const uint32_t off4 = lane_env * 4u;             // its byte offset in a 4-byte column
+    const uint64_t col = d.n_pad;                    // engine column stride (words)
     for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {  // wave-uniform
-        const uint64_t i0 = base + (uint64_t)threadIdx.x * VEC;
+        // uniform (scalar) bases of this block pass
+        float* const bx = d.base + base;
+        const uint32_t* const ba = act + base;
+        const uint64_t left = d.n - base;
+        const uint32_t rem = left < kPerBlock ? (uint32_t)left : (uint32_t)kPerBlock;
         CartPoleLane s[VEC];
         uint32_t a[VEC];
         bool valid[VEC];
         float r[VEC];
         uint32_t dn[VEC], tr[VEC];
-        const bool full = i0 + VEC <= d.n;
-        if (VEC == 4 && full) {
-            // engine columns are padded to n_pad, caller buffers were checked for 16-B alignment
-            float4 vx = *reinterpret_cast<const float4*>(d.x() + i0);
-            float4 vxd = *reinterpret_cast<const float4*>(d.xd() + i0);
-            float4 vth = *reinterpret_cast<const float4*>(d.th() + i0);
-            float4 vthd = *reinterpret_cast<const float4*>(d.thd() + i0);
-            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr() + i0);
-            uint4 va = *reinterpret_cast<const uint4*>(act + i0);
-            s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x};
-            s[1 % VEC] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
-            s[2 % VEC] = {vx.z, vxd.z, vth.z, vthd.z, vc.z};
-            s[3 % VEC] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
-            a[0] = va.x; a[1 % VEC] = va.y; a[2 % VEC] = va.z; a[3 % VEC] = va.w;
+        const bool in = lane_env < rem;  // the host launches VEC = 4 only when n % 4 == 0: a lane is wholly in or out
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) valid[k] = true;
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                uint64_t i = i0 + k;
-                valid[k] = i < d.n;
-                if (valid[k]) {
-                    s[k] = {d.x()[i], d.xd()[i], d.th()[i], d.thd()[i], d.ctr()[i]};
-                    a[k] = act[i];
-                } else {
-                    s[k] = {0.f, 0.f, 0.f, 0.f, 0u};
-                    a[k] = 0u;
-                }
+        for (int k = 0; k < VEC; ++k) { valid[k] = in; s[k] = {0.f, 0.f, 0.f, 0.f, 0u}; a[k] = 0u; }
+        if (in) {
+            if (VEC == 4) {
+                // engine columns are padded to n_pad, caller buffers were checked for 16-B alignment.
+                // theta, theta_dot and the action first: the sin/cos polynomial can start while x, x_dot, ctr are in flight
+                float4 vth = *at<float4>(bx + 2 * col, off4);
+                float4 vthd = *at<float4>(bx + 3 * col, off4);
+                uint4 va = *at<uint4>(ba, off4);
+                float4 vx = *at<float4>(bx, off4);
+                float4 vxd = *at<float4>(bx + col, off4);
+                uint4 vc = *at<uint4>(bx + 4 * col, off4);
+                s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x};
+                s[1 % VEC] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
+                s[2 % VEC] = {vx.z, vxd.z, vth.z, vthd.z, vc.z};
+                s[3 % VEC] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
+                a[0] = va.x; a[1 % VEC] = va.y; a[2 % VEC] = va.z; a[3 % VEC] = va.w;
+            } else {
+                s[0] = {*at<float>(bx, off4), *at<float>(bx + col, off4), *at<float>(bx + 2 * col, off4), *at<float>(bx + 3 * col, off4),
+                        *at<uint32_t>(bx + 4 * col, off4)};
+                a[0] = *at<uint32_t>(ba, off4);
             }
         }
         const uint64_t wave_first = base + (uint64_t)(threadIdx.x & ~63) * VEC;
         finished += cartpole_wave_step<VEC, EULER, SB, RESET>(d, s, a, valid, r, dn, tr, wave_first, lds, bad);
 
-        if (VEC == 4 && full) {
-            st4<NT>(d.x() + i0, s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
-            st4<NT>(d.xd() + i0, s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
-            st4<NT>(d.th() + i0, s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
-            st4<NT>(d.thd() + i0, s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
-            st4u<NT>(d.ctr() + i0, s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr);
-            if (obs_out) {
-                *reinterpret_cast<float4*>(obs_out + i0) = make_float4(s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
-                *reinterpret_cast<float4*>(obs_out + d.n + i0) = make_float4(s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
-                *reinterpret_cast<float4*>(obs_out + 2 * d.n + i0) = make_float4(s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
-                *reinterpret_cast<float4*>(obs_out + 3 * d.n + i0) = make_float4(s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
-            }
-            if (rew) st4<NT>(rew + i0, r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
-            if (done_out)
-                st1u<NT>(reinterpret_cast<uint32_t*>(done_out + i0), dn[0] | (dn[1 % VEC] << 8) | (dn[2 % VEC] << 16) | (dn[3 % VEC] << 24));
-            if (trunc_out)
-                st1u<NT>(reinterpret_cast<uint32_t*>(trunc_out + i0), tr[0] | (tr[1 % VEC] << 8) | (tr[2 % VEC] << 16) | (tr[3 % VEC] << 24));
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                uint64_t i = i0 + k;
-                if (valid[k]) {
-                    d.x()[i] = s[k].x; d.xd()[i] = s[k].xd; d.th()[i] = s[k].th; d.thd()[i] = s[k].thd; d.ctr()[i] = s[k].ctr;
-                    if (obs_out) {
-                        obs_out[i] = s[k].x; obs_out[d.n + i] = s[k].xd;
-                        obs_out[2 * d.n + i] = s[k].th; obs_out[3 * d.n + i] = s[k].thd;
-                    }
-                    if (rew) rew[i] = r[k];
-                    if (done_out) done_out[i] = (uint8_t)dn[k];
-                    if (trunc_out) trunc_out[i] = (uint8_t)tr[k];
+        if (in) {
+            if (VEC == 4) {
+                st4<NT>(at<float>(bx, off4), s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
+                st4<NT>(at<float>(bx + col, off4), s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
+                st4<NT>(at<float>(bx + 2 * col, off4), s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
+                st4<NT>(at<float>(bx + 3 * col, off4), s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
+                st4u<NT>(at<uint32_t>(bx + 4 * col, off4), s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr);
+                if (obs_out) {
+                    float* const bo = obs_out + base;
+                    *at<float4>(bo, off4) = make_float4(s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
+                    *at<float4>(bo + d.n, off4) = make_float4(s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
+                    *at<float4>(bo + 2 * d.n, off4) = make_float4(s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
+                    *at<float4>(bo + 3 * d.n, off4) = make_float4(s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
                 }
+                if (rew) st4<NT>(at<float>(rew + base, off4), r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+                if (done_out)
+                    st1u<NT>(at<uint32_t>(done_out + base, lane_env), dn[0] | (dn[1 % VEC] << 8) | (dn[2 % VEC] << 16) | (dn[3 % VEC] << 24));
+                if (trunc_out)
+                    st1u<NT>(at<uint32_t>(trunc_out + base, lane_env), tr[0] | (tr[1 % VEC] << 8) | (tr[2 % VEC] << 16) | (tr[3 % VEC] << 24));
+            } else {
+                *at<float>(bx, off4) = s[0].x; *at<float>(bx + col, off4) = s[0].xd; *at<float>(bx + 2 * col, off4) = s[0].th;
+                *at<float>(bx + 3 * col, off4) = s[0].thd; *at<uint32_t>(bx + 4 * col, off4) = s[0].ctr;
+                if (obs_out) {
+                    float* const bo = obs_out + base;
+                    *at<float>(bo, off4) = s[0].x; *at<float>(bo + d.n, off4) = s[0].xd;
+                    *at<float>(bo + 2 * d.n, off4) = s[0].th; *at<float>(bo + 3 * d.n, off4) = s[0].thd;
+                }
+                if (rew) *at<float>(rew + base, off4) = r[0];
+                if (done_out) *at<uint8_t>(done_out + base, lane_env) = (uint8_t)dn[0];
+                if (trunc_out) *at<uint8_t>(trunc_out + base, lane_env) = (uint8_t)tr[0];
             }
         }
     }
@@ -454,8 +464,7 @@ struct CartPoleEnv final : Env {
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
         const uint32_t* act = static_cast<const uint32_t*>(actions);
-        bool vec_ok = aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) &&
-                      (obs_out == nullptr || (aligned(obs_out, 16) && n % 4 == 0));
+        bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
         dim3 gv(grid_for((n + 3) / 4)), gs(grid_for(n));
         if (auto_reset) {
             if (vec_ok) launch_step<4, true>(gv, act, obs_out, reward, done, trunc);

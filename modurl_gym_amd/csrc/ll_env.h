@@ -25,14 +25,19 @@ enum Col : int {
     C_STEP = 64,
     C_EPISODE = 65,
     C_SEQ = 66,
-    C_CONTACT = 67,    // + 16*s : KEY SEQ LNX LNY LPX LPY P0X P0Y P0N P0T P1X P1Y P1N P1T ID0 ID1
-    C_COUNT = 67 + 16 * kSlots
+    C_CONTACT = 67,    // + 16*s : KEY SEQ LNX LNY LPX LPY P0X P0Y P0N P0T P1X P1Y P1N P1T IDS TOI
+                       //   KEY bits: 0 exists, 1 touching, 2 enabled, 3-4 body, 5-8 edge, 9-10 manifold type, 11-12 pointCount,
+                       //             13 toiFlag, 14-17 toiCount (the last two and TOI only matter inside a step, see C_MID)
+                       //   IDS = contact-feature ids of both manifold points, 16 bits each
+    C_MID = 67 + 16 * kSlots,  // state of an unfinished SolveTOI between the launches of one step (solve_toi_part):
+                               //   + 4*i : sweep c0.x c0.y a0 alpha0 of body i; + 12 : gA
+    C_COUNT = C_MID + 13
 };
 
 enum Flag : uint32_t {
     F_AWAKE0 = 1u << 0, F_GAME_OVER = 1u << 3, F_LEG0 = 1u << 4, F_LEG1 = 1u << 5, F_HAS_WORLD = 1u << 6,
     F_DETERMINISTIC = 1u << 7, F_NEW_CONTACTS = 1u << 8, F_PENDING0 = 1u << 9, F_STEPPED = 1u << 12,
-    F_PREV_SOME = 1u << 13, F_NCONTACT_SHIFT = 16
+    F_PREV_SOME = 1u << 13, F_TOUCHING = 1u << 14 /* some cached contact is touching (worklist bucketing) */, F_NCONTACT_SHIFT = 16
 };
 
 struct LLDev {
@@ -65,7 +70,15 @@ struct EnvRegs {  // LunarLanderV3 fields beside the world (lunar_lander.rs:232-
 
 #define ST(col) d.st[(uint64_t)(col) * d.n_pad + i]
 
-__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e) {
+// both contact-feature ids of a manifold in one word (every field is < 16: vertex / face indices < 8, types 0 / 1)
+__device__ __forceinline__ uint32_t cf16(CF a) { return (uint32_t)a.indexA | ((uint32_t)a.indexB << 4) | ((uint32_t)a.typeA << 8) | ((uint32_t)a.typeB << 12); }
+__device__ __forceinline__ CF cf16_unpack(uint32_t u) {
+    CF a; a.indexA = (uint8_t)(u & 15u); a.indexB = (uint8_t)((u >> 4) & 15u); a.typeA = (uint8_t)((u >> 8) & 15u); a.typeB = (uint8_t)((u >> 12) & 15u);
+    return a;
+}
+
+// mid = true: continue an unfinished SolveTOI (the env was stored by ll_store(..., mid = true) earlier in this step)
+__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e, bool mid = false) {
     const uint32_t flags = ST(C_FLAGS);
     for (int b = 0; b < 3; ++b) {
         Body& bd = w.b[b];
@@ -79,6 +92,10 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
         bd.xf.q = rot_set(bd.sw.a);
         bd.sw.localCenter = d.k.localCenter[b == 0 ? 0 : 1];
         bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a; bd.sw.alpha0 = 0.0f;
+        if (mid) {
+            bd.sw.c0 = mk(as_f32(ST(C_MID + 4 * b + 0)), as_f32(ST(C_MID + 4 * b + 1)));
+            bd.sw.a0 = as_f32(ST(C_MID + 4 * b + 2)); bd.sw.alpha0 = as_f32(ST(C_MID + 4 * b + 3));
+        }
         bd.force = mk(0.0f, 0.0f); bd.torque = 0.0f;
         bd.awake = (flags >> b) & 1u;
         bd.islandFlag = false;
@@ -94,6 +111,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     }
     for (int q = 0; q < kEdges; ++q) w.smooth[q] = as_f32(ST(C_SMOOTH + q));
     w.next_seq = ST(C_SEQ);
+    w.gA = mid ? as_f32(ST(C_MID + 12)) : 0.0f;
     w.pending = (flags >> 9) & 7u;
     w.newContacts = flags & F_NEW_CONTACTS;
     w.stepped_once = flags & F_STEPPED;
@@ -118,9 +136,11 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
             ct.m.points[p].localPoint = mk(as_f32(ST(c + 6 + 4 * p)), as_f32(ST(c + 7 + 4 * p)));
             ct.m.points[p].normalImpulse = as_f32(ST(c + 8 + 4 * p));
             ct.m.points[p].tangentImpulse = as_f32(ST(c + 9 + 4 * p));
-            ct.m.points[p].id = cf_unpack(ST(c + 14 + p));
         }
+        const uint32_t ids = ST(c + 14);
+        ct.m.points[0].id = cf16_unpack(ids); ct.m.points[1].id = cf16_unpack(ids >> 16);
         ct.toiCount = 0; ct.toi = 1.0f;
+        if (mid) { ct.toiFlag = (key >> 13) & 1u; ct.toiCount = (int)((key >> 14) & 15u); ct.toi = as_f32(ST(c + 15)); }
     }
     e.prev_shaping = as_f32(ST(C_PREV));
     e.prev_some = flags & F_PREV_SOME;
@@ -130,8 +150,8 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     e.deterministic = flags & F_DETERMINISTIC;
 }
 
-__device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e) {
-    uint32_t flags = 0, ncont = 0;
+__device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e, bool mid = false) {
+    uint32_t flags = 0, ncont = 0, touching = 0;
     for (int b = 0; b < 3; ++b) {
         const Body& bd = w.b[b];
         const int c = C_BODY + 9 * b;
@@ -144,7 +164,12 @@ __device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World
         if (bd.awake) flags |= 1u << b;
         ST(C_FAT + 4 * b + 0) = as_u32(w.fat[b].lo.x); ST(C_FAT + 4 * b + 1) = as_u32(w.fat[b].lo.y);
         ST(C_FAT + 4 * b + 2) = as_u32(w.fat[b].hi.x); ST(C_FAT + 4 * b + 3) = as_u32(w.fat[b].hi.y);
+        if (mid) {
+            ST(C_MID + 4 * b + 0) = as_u32(bd.sw.c0.x); ST(C_MID + 4 * b + 1) = as_u32(bd.sw.c0.y);
+            ST(C_MID + 4 * b + 2) = as_u32(bd.sw.a0); ST(C_MID + 4 * b + 3) = as_u32(bd.sw.alpha0);
+        }
     }
+    if (mid) ST(C_MID + 12) = as_u32(w.gA);
     for (int j = 0; j < 2; ++j) {
         const int c = C_JOINT + 5 * j;
         ST(c + 0) = as_u32(w.jt[j].impulse.x); ST(c + 1) = as_u32(w.jt[j].impulse.y);
@@ -160,22 +185,25 @@ __device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World
             const Contact& ct = w.ct[s];
             const int c = C_CONTACT + 16 * s;
             if (!ct.exists) { ST(c + 0) = 0u; continue; }
+            touching |= ct.touching ? 1u : 0u;
             ST(c + 0) = 1u | (ct.touching ? 2u : 0u) | (ct.enabled ? 4u : 0u) | ((uint32_t)ct.body << 3) | ((uint32_t)ct.edge << 5) |
-                        ((uint32_t)ct.m.type << 9) | ((uint32_t)ct.m.pointCount << 11);
+                        ((uint32_t)ct.m.type << 9) | ((uint32_t)ct.m.pointCount << 11) |
+                        (mid ? ((ct.toiFlag ? 1u : 0u) << 13) | (((uint32_t)ct.toiCount & 15u) << 14) : 0u);
             ST(c + 1) = ct.seq;
             ST(c + 2) = as_u32(ct.m.localNormal.x); ST(c + 3) = as_u32(ct.m.localNormal.y);
             ST(c + 4) = as_u32(ct.m.localPoint.x); ST(c + 5) = as_u32(ct.m.localPoint.y);
             for (int p = 0; p < 2; ++p) {
                 ST(c + 6 + 4 * p) = as_u32(ct.m.points[p].localPoint.x); ST(c + 7 + 4 * p) = as_u32(ct.m.points[p].localPoint.y);
                 ST(c + 8 + 4 * p) = as_u32(ct.m.points[p].normalImpulse); ST(c + 9 + 4 * p) = as_u32(ct.m.points[p].tangentImpulse);
-                ST(c + 14 + p) = cf_pack(ct.m.points[p].id);
             }
+            ST(c + 14) = cf16(ct.m.points[0].id) | (cf16(ct.m.points[1].id) << 16);
+            if (mid) ST(c + 15) = as_u32(ct.toi);
         }
     }
     flags |= (w.game_over ? F_GAME_OVER : 0u) | (w.legs[0] ? F_LEG0 : 0u) | (w.legs[1] ? F_LEG1 : 0u) |
              (e.has_world ? F_HAS_WORLD : 0u) | (e.deterministic ? F_DETERMINISTIC : 0u) |
              (w.newContacts ? F_NEW_CONTACTS : 0u) | ((w.pending & 7u) << 9) | (w.stepped_once ? F_STEPPED : 0u) |
-             (e.prev_some ? F_PREV_SOME : 0u) | (ncont << F_NCONTACT_SHIFT);
+             (e.prev_some ? F_PREV_SOME : 0u) | (touching ? F_TOUCHING : 0u) | (ncont << F_NCONTACT_SHIFT);
     ST(C_FLAGS) = flags;
     ST(C_PREV) = as_u32(e.prev_shaping);
     ST(C_WIND) = (uint32_t)e.wind_idx; ST(C_TORQUE) = (uint32_t)e.torque_idx;
@@ -273,13 +301,31 @@ __device__ __forceinline__ void ll_post_step(const Body& lander, bool game_over,
     e.step += 1u;
 }
 
-// step(), lunar_lander.rs:919-1167.  disp = the two raw U(-1,1) draws of :973-974.
-__device__ __forceinline__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
-                            float disp1, float state[8], float& reward, uint32_t& done) {
+// step(), lunar_lander.rs:919-1167, in resumable pieces (disp = the two raw U(-1,1) draws of :973-974):
+//   ll_step_begin    : wind / engines (:926-1048) and world.step (:1066) up to and including the first `toi_budget`
+//                      sub-steps of its continuous-collision phase; returns whether world.step is complete
+//   ll_step_continue : `toi_budget` more sub-steps (< 0: all that remain)
+//   ll_step_finish   : the tail of world.step, observation, reward, termination (:1094-1167)
+// ll_env_step = begin(all) + finish.  m_power / s_power are functions of the action alone (:979-981, :1019-1024).
+__device__ __forceinline__ bool ll_step_begin(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
+                                              float disp1, int toi_budget) {
     float m_power, s_power;
     ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, k, action, disp0, disp1, m_power, s_power);
-    world_step(w, tab, k, mem);  // :1066
+    world_step_begin(w, tab, k, mem);
+    return solve_toi_part(w, tab, k, mem, kStepDt, true, toi_budget);
+}
+__device__ __forceinline__ bool ll_step_continue(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, int toi_budget) {
+    return solve_toi_part(w, tab, k, mem, kStepDt, false, toi_budget);
+}
+__device__ __forceinline__ void ll_step_finish(World& w, EnvRegs& e, uint32_t action, float state[8], float& reward, uint32_t& done) {
+    world_step_end(w);
+    const float m_power = action == 2u ? 1.0f : 0.0f, s_power = (action == 1u || action == 3u) ? 1.0f : 0.0f;
     ll_post_step(w.b[0], w.game_over, w.legs[0], w.legs[1], e, m_power, s_power, state, reward, done);
+}
+__device__ __forceinline__ void ll_env_step(World& w, EnvRegs& e, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, uint32_t action, float disp0,
+                            float disp1, float state[8], float& reward, uint32_t& done) {
+    (void)ll_step_begin(w, e, tab, k, mem, action, disp0, disp1, -1);  // :1066
+    ll_step_finish(w, e, action, state, reward, done);
 }
 
 // world/terrain/lander/legs construction shared by reset() (:733-908) and reset_deterministic() (:1256-1438)

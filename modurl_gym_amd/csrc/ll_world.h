@@ -33,6 +33,7 @@ struct World {
     float smooth[kEdges];   // terrain heights smooth_y[0..10] (lunar_lander.rs:772-774)
     AABB fat[3];            // broad-phase AABBs of the three polygon proxies
     uint32_t next_seq;
+    float gA;               // b2World::SolveTOI: alpha0 of the static ground's sweep (its c0/a0 never move; only alpha0 ratchets)
     uint32_t pending;       // bits 0..2: proxy of body i waits in the move buffer (test seam only)
     bool newContacts, stepped_once;
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
@@ -954,17 +955,26 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
 }
 
 // ---- b2World::SolveTOI ----------------------------------------------------------------------------------
-LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt) {
-    for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
-    bool any = false;
-    for (int s = 0; s < kSlots; ++s) {
-        Contact& c = w.ct[s];
-        if (!c.exists) continue;
-        any = true;
-        c.toiFlag = false; c.islandFlag = false; c.toiCount = 0; c.toi = 1.0f;
+// Resumable: the reference's loop "evaluate the invalidated times of impact, take the earliest, sub-step that body,
+// repeat" runs `budget` sub-steps (< 0: to the end) and reports whether it finished.  Everything the loop carries
+// from one iteration to the next lives in World (sweeps incl. alpha0, per-contact toi / toiFlag / toiCount /
+// enabled, gA), so a later call with first = false continues exactly where this one stopped — the kernels use that
+// to hand the (few) environments that need sub-steps to follow-up launches over compacted lists, instead of letting
+// every lane of a wave wait for the slowest one.  Same operations in the same order either way.
+LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, bool first, int budget) {
+    if (first) {
+        for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
+        bool any = false;
+        for (int s = 0; s < kSlots; ++s) {
+            Contact& c = w.ct[s];
+            if (!c.exists) continue;
+            any = true;
+            c.toiFlag = false; c.islandFlag = false; c.toiCount = 0; c.toi = 1.0f;
+        }
+        w.gA = 0.0f;
+        if (!any) return true;
     }
-    if (!any) return;
-    float gA = 0.0f;  // alpha0 of the static ground's sweep (its c0/a0 never move; only alpha0 ratchets)
+    float gA = w.gA;
     for (;;) {
         int minSlot = -1;
         float minAlpha = 1.0f;
@@ -1009,7 +1019,9 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
             const float alpha = c.toi;
             if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
         }
-        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) break;
+        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) { w.gA = gA; return true; }
+        if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
+        if (budget > 0) --budget;
 
         Contact& minContact = w.ct[minSlot];
         const int dyn = minContact.body;
@@ -1079,8 +1091,9 @@ LLD void solve_toi(World& w, const PolyTab& tab, const LLConst& k, const CSolver
     }
 }
 
-// b2World::Step(1/50, 180, 60)
-LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem) {
+// b2World::Step(1/50, 180, 60) in three pieces: everything before SolveTOI, SolveTOI (resumable, above), the tail.
+constexpr float kStepDt = 1.0f / 50.0f;
+LLD void world_step_begin(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem) {
     if (w.newContacts) {
         int order[3], n = 0;
         for (int i = 0; i < 3; ++i)
@@ -1089,7 +1102,7 @@ LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolve
         w.pending = 0;
         w.newContacts = false;
     }
-    const float dt = 1.0f / 50.0f;
+    const float dt = kStepDt;
     const float inv_dt = 1.0f / dt;
     const float dtRatio = (w.stepped_once ? inv_dt : 0.0f) * dt;
     LL_STAMP(0);
@@ -1097,10 +1110,16 @@ LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolve
     LL_STAMP(1);
     solve_island(w, tab, k, mem, dt, inv_dt, dtRatio);
     LL_STAMP(6);
-    solve_toi(w, tab, k, mem, dt);
+}
+LLD void world_step_end(World& w) {
     LL_STAMP(7);
     w.stepped_once = true;
     for (int i = 0; i < 3; ++i) { w.b[i].force = mk(0.0f, 0.0f); w.b[i].torque = 0.0f; }
+}
+LLD void world_step(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem) {
+    world_step_begin(w, tab, k, mem);
+    (void)solve_toi_part(w, tab, k, mem, kStepDt, true, -1);
+    world_step_end(w);
 }
 
 }  // namespace ll

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
     CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
     unsigned long fast_steps = 0, general_steps = 0;
-    int max_slots = 0; unsigned long hist[kSlots + 1] = {0};
+    int max_slots = 0, max_rounds = 0; unsigned long hist[kSlots + 1] = {0}, round_hist[8] = {0};
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
     for (uint64_t i = 0; i < n; ++i) {
         World w; EnvRegs e; float state[8];
@@ -76,10 +76,26 @@ int main(int argc, char** argv) {
                 if (ll_free_env_step(d, i, f, e, tab, act[i], d0, d1, state, reward, done)) { ll_free_store(d, i, f, e); fast = true; fast_steps++; }
             }
             if (!fast) {
+                // same structure as ll_general_kernel + the ll_toi_kernel rounds: world.step up to its first
+                // time-of-impact evaluation, then one sub-step per "launch", the environment going through its
+                // mid-step columns (ll_store / ll_load with mid = true) in between, as on the GPU
                 World w; EnvRegs e;
                 ll_load(d, i, w, e);
                 ll_dispersion(d, i, e, d0, d1);
-                ll_env_step(w, e, tab, d.k, mem, act[i], d0, d1, state, reward, done);
+                bool fin = ll_step_begin(w, e, tab, d.k, mem, act[i], d0, d1, 0);
+                int rounds = 0;
+                while (!fin) {
+                    ll_store(d, i, w, e, true);
+                    World w2; EnvRegs e2;
+                    ll_load(d, i, w2, e2, true);
+                    w2.overflow = w.overflow;
+                    w = w2; e = e2;
+                    fin = ll_step_continue(w, tab, d.k, mem, rounds < 3 ? 1 : -1);
+                    ++rounds;
+                }
+                if (rounds > max_rounds) max_rounds = rounds;
+                round_hist[rounds < 7 ? rounds : 7]++;
+                ll_step_finish(w, e, act[i], state, reward, done);
                 if (w.overflow) overflow++;
                 { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
                 ll_store(d, i, w, e);
@@ -105,6 +121,9 @@ int main(int argc, char** argv) {
     printf("fast-path steps %lu, general-path steps %lu\n", fast_steps, general_steps);
     printf("max simultaneous cached contacts %d; histogram:", max_slots);
     for (int q = 0; q <= kSlots; ++q) printf(" %lu", hist[q]);
+    printf("\n");
+    printf("time-of-impact rounds per general step (max %d):", max_rounds);
+    for (int q = 0; q < 8; ++q) printf(" %lu", round_hist[q]);
     printf("\n");
     ora_vec_free(ov);
     return mism ? 1 : 0;
