@@ -34,7 +34,14 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
 constexpr int kSolverCap = 8;            // touching contacts one island may hold (LDS: 8 x 64 lanes x 124 B = 62 KB)
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
-enum { L_GENERAL = 0, L_RESET = 1, L_RESET_SLOW = 2, L_COUNT = 3 };  // device-built lists (LLDev::work_list / work_count)
+// Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
+//   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
+//                the front (count L_GENERAL), envs with one from the back (count L_GENERAL_T), so the waves of the
+//                worklist kernel hold environments of one kind (180 joint-only sweeps vs. sweeps with contact constraints).
+//   L_RESET      finished envs to reset (register-only fast path); L_RESET_SLOW: resets the fast path declined
+//   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
+constexpr int kToiRounds = 4;
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_TOI0 = 4, L_COUNT = L_TOI0 + kToiRounds };
 
 struct LLIo {
     const uint32_t* act;
@@ -63,6 +70,18 @@ __device__ __forceinline__ void ll_push(const LLDev& d, int which, bool want, ui
     if (want) d.work_list[(uint64_t)which * d.n_pad + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
 }
 
+// the same from the back of list `which_list` (length kept in count slot `which_count`)
+__device__ __forceinline__ void ll_push_back(const LLDev& d, int which_list, int which_count, bool want, uint32_t entry) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(d.work_count + which_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) d.work_list[(uint64_t)which_list * d.n_pad + (d.n_pad - 1u - (base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))))] = entry;
+}
+
 // done-mask reduction for mgym_episode_count: ballot + popcount per wave pass, one fire-and-forget atomic per wave at the end
 __device__ __forceinline__ void ll_flush_done(const LLDev& d, uint32_t finished) {
     if ((threadIdx.x & 63) == 0 && finished)
@@ -83,9 +102,10 @@ ll_free_kernel(LLDev d, LLIo io) {
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // wave-uniform trip count
         const uint64_t i = base + threadIdx.x;
         const bool valid = i < d.n;
-        bool to_general = false, to_reset = false, is_done = false;
+        bool to_general = false, to_reset = false, is_done = false, touching = false;
         if (valid) {
             const uint32_t flags = ST(C_FLAGS);
+            touching = flags & F_TOUCHING;
             if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
                 if (io.rew) io.rew[i] = 0.0f;
@@ -111,7 +131,8 @@ ll_free_kernel(LLDev d, LLIo io) {
                 }
             }
         }
-        ll_push(d, L_GENERAL, to_general, (uint32_t)i);
+        ll_push(d, L_GENERAL, to_general && !touching, (uint32_t)i);
+        ll_push_back(d, L_GENERAL, L_GENERAL_T, to_general && touching, (uint32_t)i);
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
         finished += (uint32_t)__popcll(__ballot(is_done));
     }
@@ -119,8 +140,125 @@ ll_free_kernel(LLDev d, LLIo io) {
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
 }
 
-// General path on a compacted population.  list != nullptr: entries of the worklist (general steps and resets);
-// list == nullptr: every env with `forced` = 0 general step, 1 reset(), 2 Testable::reset_deterministic.
+// outputs of a finished step + its deferred reset (shared by the worklist kernels)
+__device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t i, const float state[8], float reward, uint32_t done) {
+    if (io.rew) io.rew[i] = reward;
+    if (io.done_out) io.done_out[i] = (uint8_t)done;
+    if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
+    ll_write_obs(d, io, i, state);
+}
+
+// Stage 2 of mgym_step, on the compacted L_GENERAL list: wind / engines, b2World::Step up to and including the first
+// evaluation of the times of impact (collide, the 180-sweep island solve, position iterations, new contacts, one
+// b2TimeOfImpact per cached contact).  ~3/4 of the environments are done at that point (no impact within the step);
+// the rest go, with their unfinished SolveTOI state in the C_MID columns, onto L_TOI0 for ll_toi_kernel.
+template <int BLK>
+__global__ void __launch_bounds__(BLK)
+ll_contact_kernel(LLDev d, LLIo io) {
+    __shared__ PolyTab tab;
+    __shared__ VConstraint s_vc[kSolverCap * BLK];
+    stage_tab(tab, d.k);
+    PConstraint l_pc[kSolverCap];
+    CSolverMem mem;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    bool not_reset = false, overflow = false;
+    uint32_t finished = 0;
+    const uint32_t* list = d.work_list + (uint64_t)L_GENERAL * d.n_pad;
+    const uint64_t c0 = d.work_count[L_GENERAL], c1 = d.work_count[L_GENERAL_T];
+    const uint64_t c0_up = (c0 + BLK - 1) / BLK * BLK;  // the touching bucket starts at a block boundary
+    const uint64_t total = c0_up + c1;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * BLK; q0 < total; q0 += (uint64_t)gridDim.x * BLK) {  // block-uniform
+        const uint64_t q = q0 + threadIdx.x;
+        const bool have = q < c0 || (q >= c0_up && q < total);
+        uint64_t i = 0;
+        bool to_toi = false, to_reset = false, is_done = false;
+        if (have) {
+            i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
+            World w; EnvRegs e;
+            ll_load(d, i, w, e);
+            if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+                not_reset = true;
+                if (io.rew) io.rew[i] = 0.0f;
+                if (io.done_out) io.done_out[i] = 0;
+                if (io.trunc_out) io.trunc_out[i] = 0;
+            } else {
+                const uint32_t action = io.act[i];
+                float d0, d1;
+                ll_dispersion(d, i, e, d0, d1);
+                if (ll_step_begin(w, e, tab, d.k, mem, action, d0, d1, 0)) {
+                    float state[8], reward; uint32_t done;
+                    ll_step_finish(w, e, action, state, reward, done);
+                    ll_store(d, i, w, e);
+                    ll_emit(d, io, i, state, reward, done);
+                    is_done = done != 0u;
+                    to_reset = d.auto_reset && done;
+                } else {
+                    ll_store(d, i, w, e, true);
+                    to_toi = true;
+                }
+                overflow |= w.overflow;
+            }
+        }
+        ll_push(d, L_TOI0, to_toi, (uint32_t)i);
+        ll_push(d, L_RESET, to_reset, (uint32_t)i);
+        finished += (uint32_t)__popcll(__ballot(is_done));
+    }
+    ll_flush_done(d, finished);
+    if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
+    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+}
+
+// Stage 3 of mgym_step, rounds r = 0 .. kToiRounds-1 over ever shorter lists: continue b2World::SolveTOI of the envs on
+// L_TOI0 + r by `budget` sub-steps (advance the body to its earliest impact, solve the TOI island, re-evaluate that body's
+// times of impact); finished envs get the tail of the step (observation, reward, termination), the others move on to
+// L_TOI0 + r + 1.  The last round runs with budget < 0 (to the end).  Per general env-step the reference does 0 sub-steps
+// 74 % of the time, 1: 17 %, 2: 7 %, >= 3: 2 % (tools/ll_work_stats.c) — inside one launch every wave would wait for its
+// slowest lane through all of them.
+template <int BLK>
+__global__ void __launch_bounds__(BLK)
+ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
+    __shared__ PolyTab tab;
+    __shared__ VConstraint s_vc[kSolverCap * BLK];
+    stage_tab(tab, d.k);
+    PConstraint l_pc[kSolverCap];
+    CSolverMem mem;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    bool overflow = false;
+    uint32_t finished = 0;
+    const uint32_t* list = d.work_list + (uint64_t)(L_TOI0 + round) * d.n_pad;
+    const uint64_t total = d.work_count[L_TOI0 + round];
+    for (uint64_t q0 = (uint64_t)blockIdx.x * BLK; q0 < total; q0 += (uint64_t)gridDim.x * BLK) {  // block-uniform
+        const uint64_t q = q0 + threadIdx.x;
+        uint64_t i = 0;
+        bool to_toi = false, to_reset = false, is_done = false;
+        if (q < total) {
+            i = list[q];
+            World w; EnvRegs e;
+            ll_load(d, i, w, e, true);
+            if (ll_step_continue(w, tab, d.k, mem, budget)) {
+                float state[8], reward; uint32_t done;
+                ll_step_finish(w, e, io.act[i], state, reward, done);
+                ll_store(d, i, w, e);
+                ll_emit(d, io, i, state, reward, done);
+                is_done = done != 0u;
+                to_reset = d.auto_reset && done;
+            } else {
+                ll_store(d, i, w, e, true);
+                to_toi = true;
+            }
+            overflow |= w.overflow;
+        }
+        if (round + 1 < kToiRounds) ll_push(d, L_TOI0 + round + 1, to_toi, (uint32_t)i);
+        ll_push(d, L_RESET, to_reset, (uint32_t)i);
+        finished += (uint32_t)__popcll(__ballot(is_done));
+    }
+    ll_flush_done(d, finished);
+    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+}
+
+// Whole general step in ONE launch (no time-of-impact rounds): the declined resets of L_RESET_SLOW (list != nullptr),
+// Testable::reset_deterministic, and the MGYM_LL_GENERAL_ONLY debugging aid.  list == nullptr: every env with
+// `forced` = 0 general step, 1 reset(), 2 Testable::reset_deterministic.
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int forced) {
@@ -298,7 +436,8 @@ struct LunarLanderEnv final : Env {
     void* work_base = nullptr;
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
-    int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the worklist kernel: 32 measured best (3.47 ms vs 3.76 ms at 64, 4.6 ms at 16): shorter per-wave maxima, half the LDS
+    int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the contact kernel
+    int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
     ~LunarLanderEnv() override {
@@ -380,11 +519,20 @@ struct LunarLanderEnv final : Env {
         case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
         }
-        const uint32_t* gl = list_ptr(L_GENERAL);
-        const uint32_t* gc = dev.work_count + L_GENERAL;
-        if (gen_block == 16) hipLaunchKernelGGL(ll_general_kernel<16>, dim3(work_grid().x * 4), dim3(16), 0, stream, dev, io, gl, gc, 0);
-        else if (gen_block == 32) hipLaunchKernelGGL(ll_general_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, gl, gc, 0);
-        else hipLaunchKernelGGL(ll_general_kernel<64>, work_grid(), dim3(64), 0, stream, dev, io, gl, gc, 0);
+        // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
+        // grid-stride inside: the list lengths only exist on the device)
+        const unsigned gb = work_grid().x * (64 / gen_block);
+        if (gen_block == 16) hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io);
+        else if (gen_block == 64) hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io);
+        else hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io);
+        for (int r = 0; r < kToiRounds; ++r) {
+            unsigned g = (work_grid().x * (64 / toi_block)) >> (r + 1);
+            if (g < 64) g = 64;
+            const int budget = r + 1 < kToiRounds ? 1 : -1;
+            if (toi_block == 16) hipLaunchKernelGGL(ll_toi_kernel<16>, dim3(g), dim3(16), 0, stream, dev, io, r, budget);
+            else if (toi_block == 64) hipLaunchKernelGGL(ll_toi_kernel<64>, dim3(g), dim3(64), 0, stream, dev, io, r, budget);
+            else hipLaunchKernelGGL(ll_toi_kernel<32>, dim3(g), dim3(32), 0, stream, dev, io, r, budget);
+        }
         if (dev.auto_reset) {  // finished envs were compacted onto L_RESET by both kernels; outputs of the step stay as written
             LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};
             launch_resets(rio, false);
