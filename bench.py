@@ -77,6 +77,7 @@ class Stepper:
         self.env.reset_device(None, None)
         self.graph = None
         self.tail_graphs = {}
+        self.timed = None
         self.t = 0
 
     def one(self, k):
@@ -96,6 +97,15 @@ class Stepper:
         if rem and rem not in self.tail_graphs:
             self.tail_graphs[rem] = self.env.graph_capture(lambda: [self.one(k) for k in range(rem)])
 
+    def build_timed_graph(self, steps):
+        """ONE graph of exactly `steps` step launches: a short timed region is then a single hipGraphLaunch (no eager
+        tail, no second replay)."""
+        self.timed = (steps, self.env.graph_capture(lambda: [self.one(k) for k in range(steps)]))
+
+    def run_timed(self, steps):
+        assert self.timed is not None and self.timed[0] == steps
+        self.env.graph_launch(self.timed[1])
+
     def run(self, steps):
         """issue exactly `steps` steps on the stream"""
         if self.launch != "graph":
@@ -110,7 +120,7 @@ class Stepper:
             self.env.graph_launch(self.tail_graphs[steps % RING])
 
     def close(self):
-        for g in [self.graph] + list(self.tail_graphs.values()):
+        for g in [self.graph] + list(self.tail_graphs.values()) + ([self.timed[1]] if self.timed else []):
             if g is not None:
                 self.env.graph_destroy(g)
         self.env.close()
@@ -233,10 +243,15 @@ def main():
         for s in steppers:
             s.run(steps)
 
+    # short timed regions (the driver runs --steps 20): ONE graph of exactly K launches with the event records inside
+    one_graph = args.launch == "graph" and args.steps <= 256
     if args.launch == "graph":
         for s in steppers:
-            s.build_graph(args.steps)   # capture + instantiate before anything is timed, whatever the warm-up length
-            s.build_graph(args.warmup)
+            s.build_graph(args.warmup)   # capture + instantiate before anything is timed, whatever the warm-up length
+            if one_graph:
+                s.build_timed_graph(args.steps)
+            else:
+                s.build_graph(args.steps)
     run(args.warmup)
     for s in steppers:
         s.env.sync()
@@ -245,7 +260,11 @@ def main():
     torch.cuda.synchronize()
     lead.env.timer_start()            # hipEvent on the launch stream
     t0 = time.perf_counter()
-    run(args.steps)                   # EXACTLY K steps
+    if one_graph:
+        for s in steppers:
+            s.run_timed(args.steps)   # EXACTLY K steps: one hipGraphLaunch
+    else:
+        run(args.steps)               # EXACTLY K steps
     ev_ms = lead.env.timer_stop()     # second hipEvent + hipEventSynchronize
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -268,7 +287,7 @@ def main():
         "config": {"workload": {"cartpole": "CartPole-v1, 1048576 envs per GPU, f32 SoA (BASELINE configs[1])",
                                 "mixed": "Mixed CartPole+MountainCar+LunarLander, 1048576 envs per GPU (BASELINE configs[4] per-GPU load)"}
                    .get(args.workload, args.workload),
-                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": f"{args.launch} (hipGraph of {RING} steps)" if args.launch == "graph" else "eager",
+                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": (f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if args.launch == "graph" else "eager",
                    "reset": "fused auto-reset in the step kernel" if args.reset == "fused" else "separate mgym_reset_done launch per step",
                    "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING},
     }
@@ -284,6 +303,19 @@ def main():
                               "avg_launch_us": dur * 1e6,
                               "note": "algorithmic bytes/env-step x envs per launch / HIP-event time per launch; at 1Mi envs the working set "
                                       "(~50 MB) is Infinity-Cache resident, see DESIGN.md for the >256 MiB run"}
+        if args.steps < 256 and args.launch == "graph":
+            # A short timed region (the driver runs --steps 20) starts on an idle stream, so its event interval carries
+            # the host's graph-launch latency (10-20 us) and the clock ramp.  Report, beside it and AFTER the timed
+            # region, the same kernel's steady per-launch time: HIP events around 30 replays of the 16-step graph.
+            lead.build_graph(480)
+            lead.run(64)
+            lead.env.sync()
+            lead.env.timer_start()
+            lead.run(480)
+            sms = lead.env.timer_stop()
+            sdur = sms * 1e-3 / 480
+            result["roofline"]["steady"] = {"avg_launch_us": sdur * 1e6, "achieved": alg / sdur / 1e9, "frac": alg / sdur / HBM_PEAK, "steps": 480,
+                                            "note": "same kernel, HIP events around 480 graph-replayed launches after the timed region"}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
