@@ -50,7 +50,10 @@ typedef enum mgym_status {
     MGYM_ERR_HIP = 4,            /* HIP runtime failure (reference: candle_core::Error from tensor ops) */
     MGYM_ERR_BAD_ARG = 5,        /* null/misaligned pointer, wrong kind */
     MGYM_ERR_NO_DEVICE = 6,      /* no gfx950 device / HIP runtime unusable: the engine has no CPU fallback */
-    MGYM_ERR_CAPACITY = 7        /* LunarLander: more simultaneous ground contacts than the per-env cache holds (12) */
+    MGYM_ERR_CAPACITY = 7        /* LunarLander: more body/ground-edge pairs than the per-env contact cache holds (12: reachable only
+                                    at horizontal speeds > 8 m/s next to the ground) or more touching contacts than the island solver
+                                    holds (9 = the geometric bound of the scene); mgym_last_error() says which.  The affected
+                                    environment's results are undefined until it is reset.  The reference has no such limit. */
 } mgym_status;
 
 typedef enum mgym_kind {

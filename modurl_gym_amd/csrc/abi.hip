@@ -306,7 +306,13 @@ int mgym_sync(mgym_env* env) {
         return MGYM_ERR_INVALID_ACTION;
     }
     if (bits & DEV_ERR_CONTACT_OVERFLOW) {
-        set_last_error("LunarLander: contact cache overflow (more than 12 simultaneous ground contacts in one environment)");
+        set_last_error("LunarLander: contact cache overflow (more than 12 body/ground-edge pairs with overlapping broad-phase boxes in one "
+                       "environment: a pair was dropped; that environment's results are undefined until it is reset)");
+        return MGYM_ERR_CAPACITY;
+    }
+    if (bits & DEV_ERR_SOLVER_OVERFLOW) {
+        set_last_error("LunarLander: island solver overflow (more than 9 touching contacts in one environment: the extra constraints were "
+                       "not solved; that environment's results are undefined until it is reset)");
         return MGYM_ERR_CAPACITY;
     }
     if (bits & DEV_ERR_NOT_RESET) {

@@ -117,7 +117,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     w.stepped_once = flags & F_STEPPED;
     w.game_over = flags & F_GAME_OVER;
     w.legs[0] = flags & F_LEG0; w.legs[1] = flags & F_LEG1;
-    w.overflow = false; w.terrain_dirty = false;
+    w.overflow = 0u; w.terrain_dirty = false;
     const uint32_t ncont = (flags >> F_NCONTACT_SHIFT) & 15u;
     for (int s = 0; s < kSlots; ++s) {
         Contact& ct = w.ct[s];
@@ -361,7 +361,7 @@ __device__ __forceinline__ void ll_build_scene(World& w, EnvRegs& e, const PolyT
     for (int j = 0; j < 2; ++j) { w.jt[j].impulse = mk(0.0f, 0.0f); w.jt[j].motorImpulse = 0.0f; w.jt[j].lowerImpulse = 0.0f; w.jt[j].upperImpulse = 0.0f; }
     for (int s = 0; s < kSlots; ++s) w.ct[s].exists = false;
     w.next_seq = 1u; w.pending = 7u; w.newContacts = true; w.stepped_once = false;
-    w.game_over = false; w.legs[0] = w.legs[1] = false; w.overflow = false;
+    w.game_over = false; w.legs[0] = w.legs[1] = false; w.overflow = 0u;
     if (random_force) {  // :845-849
         float force_x = u_force0 * (INITIAL_RANDOM - (-INITIAL_RANDOM)) + (-INITIAL_RANDOM);
         float force_y = u_force1 * (INITIAL_RANDOM - (-INITIAL_RANDOM)) + (-INITIAL_RANDOM);

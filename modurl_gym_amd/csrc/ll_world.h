@@ -37,7 +37,7 @@ struct World {
     uint32_t pending;       // bits 0..2: proxy of body i waits in the move buffer (test seam only)
     bool newContacts, stepped_once;
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
-    bool overflow;            // contact cache exhausted (reported through the sticky status)
+    uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
 };
 
@@ -127,7 +127,7 @@ LLD void add_pair(World& w, int edge, int body) {
     int s = -1;
     for (int k = 0; k < kSlots; ++k)
         if (!w.ct[k].exists) { s = k; break; }
-    if (s < 0) { w.overflow = true; return; }
+    if (s < 0) { w.overflow |= 1u; return; }
     Contact& c = w.ct[s];
     c.exists = true; c.touching = false; c.enabled = true; c.islandFlag = false; c.toiFlag = false;
     c.seq = w.next_seq++;
@@ -281,7 +281,7 @@ LLD bool pos_same(const Pos& a, const Pos& b) {
 
 LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
     s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
-    if (count > mem.cap) { w.overflow = true; count = mem.cap; }
+    if (count > mem.cap) { w.overflow |= 2u; count = mem.cap; }
     s.count = count;
     for (int i = 0; i < count; ++i) {
         Contact& contact = w.ct[slots[i]];

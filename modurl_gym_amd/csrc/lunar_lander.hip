@@ -22,8 +22,8 @@ namespace mgym {
 
 
 __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
-    if (threadIdx.x < 2 * kMaxPoly) {
-        int p = threadIdx.x / kMaxPoly, q = threadIdx.x % kMaxPoly;
+    for (int t = threadIdx.x; t < 2 * kMaxPoly; t += blockDim.x) {  // blocks may be narrower than the table
+        int p = t / kMaxPoly, q = t % kMaxPoly;
         tab.v[p][q] = k.poly_v[p][q];
         tab.n[p][q] = k.poly_n[p][q];
     }
@@ -32,7 +32,10 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 }
 
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
-constexpr int kSolverCap = 8;            // touching contacts one island may hold (LDS: 8 x 64 lanes x 124 B = 62 KB)
+// Touching contacts one island may hold.  9 is the geometric bound of this scene: a body's polygon spans < 2 m (lander
+// 1.13 m, leg diagonal 0.55 m) while terrain edges are 2 m wide, so it can touch at most two adjacent terrain edges plus
+// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (LDS: 9 x 32 lanes x 124 B = 35.7 KB per block.)
+constexpr int kSolverCap = 9;
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 // Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
 //   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
@@ -161,7 +164,8 @@ ll_contact_kernel(LLDev d, LLIo io) {
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
-    bool not_reset = false, overflow = false;
+    bool not_reset = false;
+    uint32_t overflow = 0u;
     uint32_t finished = 0;
     const uint32_t* list = d.work_list + (uint64_t)L_GENERAL * d.n_pad;
     const uint64_t c0 = d.work_count[L_GENERAL], c1 = d.work_count[L_GENERAL_T];
@@ -205,7 +209,8 @@ ll_contact_kernel(LLDev d, LLIo io) {
     }
     ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
-    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
 }
 
 // Stage 3 of mgym_step, rounds r = 0 .. kToiRounds-1 over ever shorter lists: continue b2World::SolveTOI of the envs on
@@ -223,7 +228,7 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
-    bool overflow = false;
+    uint32_t overflow = 0u;
     uint32_t finished = 0;
     const uint32_t* list = d.work_list + (uint64_t)(L_TOI0 + round) * d.n_pad;
     const uint64_t total = d.work_count[L_TOI0 + round];
@@ -248,12 +253,13 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
             }
             overflow |= w.overflow;
         }
-        if (round + 1 < kToiRounds) ll_push(d, L_TOI0 + round + 1, to_toi, (uint32_t)i);
+        if (round + 1 < kToiRounds) ll_push(d, L_TOI0 + round + 1, to_toi, (uint32_t)i);  // (never set when budget < 0)
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
         finished += (uint32_t)__popcll(__ballot(is_done));
     }
     ll_flush_done(d, finished);
-    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
 }
 
 // Whole general step in ONE launch (no time-of-impact rounds): the declined resets of L_RESET_SLOW (list != nullptr),
@@ -269,7 +275,8 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
-    bool not_reset = false, overflow = false;
+    bool not_reset = false;
+    uint32_t overflow = 0u;
     uint32_t finished = 0;
     const uint64_t total = list ? (uint64_t)*count : d.n;
     // block-uniform trip count (the deferred-reset push below is a wave-level collective)
@@ -330,7 +337,8 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     }
     ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
-    if (__any(overflow) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
+    if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
 }
 
 // reset() on a compacted list (or on every env when list == nullptr): draw the new episode's scene
@@ -438,6 +446,7 @@ struct LunarLanderEnv final : Env {
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the contact kernel
     int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
+    int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : kToiRounds;  // 1 .. kToiRounds launches of ll_toi_kernel
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
     ~LunarLanderEnv() override {
@@ -522,16 +531,22 @@ struct LunarLanderEnv final : Env {
         // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
         // grid-stride inside: the list lengths only exist on the device)
         const unsigned gb = work_grid().x * (64 / gen_block);
-        if (gen_block == 16) hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io);
-        else if (gen_block == 64) hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io);
-        else hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io);
-        for (int r = 0; r < kToiRounds; ++r) {
+        switch (gen_block) {
+        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, stream, dev, io); break;
+        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io); break;
+        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io); break;
+        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io); break;
+        }
+        for (int r = 0; r < toi_rounds; ++r) {
             unsigned g = (work_grid().x * (64 / toi_block)) >> (r + 1);
             if (g < 64) g = 64;
-            const int budget = r + 1 < kToiRounds ? 1 : -1;
-            if (toi_block == 16) hipLaunchKernelGGL(ll_toi_kernel<16>, dim3(g), dim3(16), 0, stream, dev, io, r, budget);
-            else if (toi_block == 64) hipLaunchKernelGGL(ll_toi_kernel<64>, dim3(g), dim3(64), 0, stream, dev, io, r, budget);
-            else hipLaunchKernelGGL(ll_toi_kernel<32>, dim3(g), dim3(32), 0, stream, dev, io, r, budget);
+            const int budget = r + 1 < toi_rounds ? 1 : -1;   // the last round runs every remaining sub-step
+            switch (toi_block) {
+            case 8: hipLaunchKernelGGL(ll_toi_kernel<8>, dim3(g), dim3(8), 0, stream, dev, io, r, budget); break;
+            case 16: hipLaunchKernelGGL(ll_toi_kernel<16>, dim3(g), dim3(16), 0, stream, dev, io, r, budget); break;
+            case 64: hipLaunchKernelGGL(ll_toi_kernel<64>, dim3(g), dim3(64), 0, stream, dev, io, r, budget); break;
+            default: hipLaunchKernelGGL(ll_toi_kernel<32>, dim3(g), dim3(32), 0, stream, dev, io, r, budget); break;
+            }
         }
         if (dev.auto_reset) {  // finished envs were compacted onto L_RESET by both kernels; outputs of the step stay as written
             LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};

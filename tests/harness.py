@@ -14,7 +14,8 @@ An adapter exposes: reset_deterministic(), set_state(obs, info), step(action) ->
 import numpy as np
 
 
-def replay(adapter, fixture, reward_tol=1e-4, obs_tol=1e-4):
+def replay(adapter, fixture, reward_tol=1e-4, obs_tol=1e-4, trace=None):
+    """trace: optional list receiving (step, action, worst |obs error|, |reward error|) per step"""
     actions, expected = fixture["actions"], fixture["expected"]
     assert len(actions) > 0 and len(actions) == len(expected)
     adapter.reset_deterministic()
@@ -36,6 +37,8 @@ def replay(adapter, fixture, reward_tol=1e-4, obs_tol=1e-4):
         dobs = np.abs(np.asarray(obs, np.float32) - exp_obs)
         assert (dobs < obs_tol).all(), f"step {i}: obs {list(obs)} vs {exp['observation']}"
         worst_obs = max(worst_obs, float(dobs.max()))
+        if trace is not None:
+            trace.append((i, action, float(dobs.max()), drew))
         worst_rew = max(worst_rew, drew)
     return worst_obs, worst_rew
 

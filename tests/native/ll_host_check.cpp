@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
                     ll_store(d, i, w, e, true);
                     World w2; EnvRegs e2;
                     ll_load(d, i, w2, e2, true);
-                    w2.overflow = w.overflow;
+                    w2.overflow |= w.overflow;
                     w = w2; e = e2;
                     fin = ll_step_continue(w, tab, d.k, mem, rounds < 3 ? 1 : -1);
                     ++rounds;
