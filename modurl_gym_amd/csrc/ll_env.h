@@ -53,6 +53,7 @@ struct LLDev {
     uint32_t* work_count;
     LLConst k;
     int auto_reset;
+    int bucket;  // worklist bucketing by F_TOUCHING
 };
 
 // lunar_lander.rs:31-58

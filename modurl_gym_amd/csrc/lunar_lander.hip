@@ -108,7 +108,7 @@ ll_free_kernel(LLDev d, LLIo io) {
         bool to_general = false, to_reset = false, is_done = false, touching = false;
         if (valid) {
             const uint32_t flags = ST(C_FLAGS);
-            touching = flags & F_TOUCHING;
+            touching = d.bucket && (flags & F_TOUCHING);
             if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
                 if (io.rew) io.rew[i] = 0.0f;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // the rest go, with their unfinished SolveTOI state in the C_MID columns, onto L_TOI0 for ll_toi_kernel.
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
-ll_contact_kernel(LLDev d, LLIo io) {
+ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kSolverCap * BLK];
     stage_tab(tab, d.k);
@@ -189,7 +189,7 @@ ll_contact_kernel(LLDev d, LLIo io) {
                 const uint32_t action = io.act[i];
                 float d0, d1;
                 ll_dispersion(d, i, e, d0, d1);
-                if (ll_step_begin(w, e, tab, d.k, mem, action, d0, d1, 0)) {
+                if (ll_step_begin(w, e, tab, d.k, mem, action, d0, d1, toi_budget)) {
                     float state[8], reward; uint32_t done;
                     ll_step_finish(w, e, action, state, reward, done);
                     ll_store(d, i, w, e);
@@ -446,7 +446,15 @@ struct LunarLanderEnv final : Env {
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the contact kernel
     int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
-    int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : kToiRounds;  // 1 .. kToiRounds launches of ll_toi_kernel
+    // Launch structure of the contact path.  Measured on MI355X (profiles/r02_lunarlander/tune_launch_structure.txt), 262 144
+    // envs, ms per step: whole world.step in the contact kernel, envs in index order 1.96 (default) | the same with
+    // touching / non-touching envs bucketed into separate waves 2.12 | time-of-impact sub-steps in 1 / 4 follow-up
+    // launches over compacted lists 2.33 / 3.02 | 16- or 8-lane blocks 2.6-3.7.  The kernel's duration is its SLOWEST
+    // wave's dependent chain (island solve + up to 5 sub-steps of ~0.16 ms each), not a throughput limit: concentrating
+    // heavy lanes (bucketing) lengthens that wave, and follow-up launches serialise the same chain behind launch
+    // boundaries and a state round trip.  The alternatives stay selectable for profiling:
+    int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : 0;       // 1: touching / non-touching envs at opposite ends of the worklist
+    int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
     ~LunarLanderEnv() override {
@@ -471,6 +479,7 @@ struct LunarLanderEnv final : Env {
         dev.disp = nullptr;
         dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err; dev.done_count = d_done;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
+        dev.bucket = bucket;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
         return MGYM_OK;
     }
@@ -532,10 +541,10 @@ struct LunarLanderEnv final : Env {
         // grid-stride inside: the list lengths only exist on the device)
         const unsigned gb = work_grid().x * (64 / gen_block);
         switch (gen_block) {
-        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, stream, dev, io); break;
-        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io); break;
-        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io); break;
-        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io); break;
+        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
         }
         for (int r = 0; r < toi_rounds; ++r) {
             unsigned g = (work_grid().x * (64 / toi_block)) >> (r + 1);

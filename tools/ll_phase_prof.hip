@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     env.cfg.enable_wind = 1; env.cfg.wind_power = 15.f; env.cfg.turbulence_power = 1.5f;
     env.n = n; env.n_pad = round_up(n, 1024);
     CK(hipStreamCreate(&env.stream)); CK(hipMalloc((void**)&env.d_err, 4)); CK(hipMemset(env.d_err, 0, 4));
+    CK(hipMalloc((void**)&env.d_done, kDoneShards * 8)); CK(hipMemset(env.d_done, 0, kDoneShards * 8));
     env.init();
     uint32_t* act; float* rew; uint8_t *dn, *tr;
     CK(hipMalloc((void**)&act, 16 * n * 4)); CK(hipMalloc((void**)&rew, n * 4)); CK(hipMalloc((void**)&dn, n)); CK(hipMalloc((void**)&tr, n));
