@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
     ap.add_argument("--reset", default="fused", choices=["fused", "separate"],
                     help="fused: auto-reset inside the step kernel; separate: step + mgym_reset_done launch")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --envs (default: BASELINE size) per GPU; strong: --total-envs fixed for the node, index-sharded over the ranks")
+    ap.add_argument("--total-envs", type=int, default=8 << 20, help="node total for --scaling strong (default 8 388 608, BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
@@ -149,6 +152,48 @@ def host_cores():
     return max(1, min(c, 64))   # `cores` reports the threads actually used; 64 bounds the OpenMP team on a big shared host
 
 
+def kernel_source_sha16(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "modurl_gym_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(key):
+    """Counter figures of profiles/pmc_traffic.json (rocprofv3 --pmc runs of this same bench.py, collected by
+    tools/profile_pmc.sh).  An entry names the kernel sources it was measured on (sha256 prefix): a record taken on other
+    sources than the ones this run executes is stale and is not reported."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(key)
+        if rec and rec.get("src_sha16") == kernel_source_sha16(rec["src_files"]):
+            return rec
+    except Exception:
+        pass
+    return None
+
+
+def lunar_roofline(n, step_s):
+    """LunarLander is bound by f32 VALU issue / dependent chains (180 Gauss-Seidel sweeps per step), not by HBM:
+    achieved = counted f32 FMA (x2) + MUL + ADD lane-operations per step (SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 x mean active
+    lanes per VALU instruction, summed over the step's kernels; profiles/pmc_traffic.json) / this run's step time,
+    against the 157.3 TFLOP/s f32 vector peak.  The HBM fraction is given for reference."""
+    alg = (107 * 4 * 2 + 46) * n   # state words always touched, R + W, + API traffic
+    out = {"bound": "valu", "peak": 157.3, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
+           "kernel": "ll_free_kernel + ll_contact_kernel + ll_reset_kernel", "avg_step_us": step_s * 1e6,
+           "hbm_for_reference": {"alg_bytes_per_step": alg, "GBps": alg / step_s / 1e9, "frac": alg / step_s / HBM_PEAK}}
+    rec = pmc_record(f"lunar_lander:{n}")
+    if rec:
+        out["achieved"] = rec["f32_flop_per_step_active_lanes"] / step_s / 1e12
+        out["frac"] = out["achieved"] / 157.3
+        out["flop_per_step_active_lanes"] = rec["f32_flop_per_step_active_lanes"]
+        out["flop_per_step_all_64_lanes"] = rec["f32_flop_per_step_lanes64"]
+        out["frac_if_all_64_lanes_counted"] = rec["f32_flop_per_step_lanes64"] / step_s / 157.3e12
+        out["counter_source"] = rec.get("source")
+    return out
+
+
 def cpu_baseline(workload, n, seed):
     """The oracle on this box's host cores: `for env in envs { env.step(a) }` over a bounded sample."""
     import numpy as np
@@ -228,15 +273,15 @@ def main():
     n_default = {"cartpole": 1 << 20, "mountain_car": 1 << 20, "mountain_car_cont": 1 << 20, "lunar_lander": 1 << 18,
                  "mixed": 1 << 20}
     n = args.envs or n_default[args.workload]
-    if args.workload == "mixed":
-        pop = mg.mixed_population(n)
-    else:
-        pop = {args.workload: n}
-    steppers, base = [], 0
-    for name, cnt in pop.items():
-        # global env ids: family blocks are laid out [family][rank][local index]
-        steppers.append(Stepper(mg, torch, name, cnt, local_rank, args.seed, base + rank * cnt, stream, args.reset, args.launch))
-        base += world * cnt
+    # this rank's handles: global env ids [family][rank][local index] (weak) or contiguous blocks of a fixed node total (strong)
+    plan = mg.population_plan(args.workload, world, rank, args.scaling, n_per_gpu=n, n_total=args.total_envs)
+    pop = {name: cnt for name, cnt, _ in plan}
+    if args.scaling == "strong" and args.workload != "mixed":
+        n = plan[0][1]
+    # one stream per family: the mixed batch's three step pipelines are independent and overlap on the device
+    streams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in plan[1:]]
+    steppers = [Stepper(mg, torch, name, cnt, local_rank, args.seed, gbase, st, args.reset, args.launch)
+                for (name, cnt, gbase), st in zip(plan, streams)]
     lead = steppers[0]
 
     def run(steps):
@@ -277,19 +322,20 @@ def main():
     for s in steppers:
         s.env.sync()                  # surfaces any sticky device-side error
 
-    total_envs = sum(pop.values()) * world
+    total_envs = sum(pop.values()) * world if args.scaling == "weak" else (args.total_envs if args.workload != "mixed" else sum(mg.mixed_population(args.total_envs).values()))
     value = total_envs * args.steps / elapsed
     result = {
         "metric": "env-steps/sec (whole node), CartPole 1M envs, at 1/2/4/8 MI355X",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"cartpole": "CartPole-v1, 1048576 envs per GPU, f32 SoA (BASELINE configs[1])",
                                 "mixed": "Mixed CartPole+MountainCar+LunarLander, 1048576 envs per GPU (BASELINE configs[4] per-GPU load)"}
                    .get(args.workload, args.workload),
                    "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": (f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if args.launch == "graph" else "eager",
                    "reset": "fused auto-reset in the step kernel" if args.reset == "fused" else "separate mgym_reset_done launch per step",
-                   "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING},
+                   "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING,
+                   "scaling": ("weak: fixed envs per GPU" if args.scaling == "weak" else f"strong: {total_envs} envs fixed for the node, contiguous index blocks per rank")},
     }
     if args.workload in ALG_BYTES:
         # dominant kernel = the step kernel; with --reset fused the timed region is K launches of it
@@ -316,24 +362,13 @@ def main():
             sdur = sms * 1e-3 / 480
             result["roofline"]["steady"] = {"avg_launch_us": sdur * 1e6, "achieved": alg / sdur / 1e9, "frac": alg / sdur / HBM_PEAK, "steps": 480,
                                             "note": "same kernel, HIP events around 480 graph-replayed launches after the timed region"}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc)).get(f"{args.workload}:{n}")
-                if rec:
-                    result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                    result["roofline"]["traffic_source"] = rec.get("source")
-            except Exception:
-                pass
+        rec = pmc_record(f"{args.workload}:{n}")
+        if rec:
+            result["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = rec.get("source")
 
     if args.workload == "lunar_lander":
-        # VALU / dependent-chain bound (180 Gauss-Seidel sweeps per step), not HBM: report the HBM fraction for
-        # completeness (state R+W as laid out: 107 always-touched words x 2 + API traffic 46 B) and say so
-        alg = (107 * 4 * 2 + 46) * n
-        dur = ev_ms * 1e-3 / args.steps
-        result["roofline"] = {"bound": "valu (f32 issue + dependent chains); hbm fraction shown for reference", "achieved": alg / dur / 1e9,
-                              "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / dur / HBM_PEAK, "traffic": None,
-                              "kernel": "ll_step_kernel", "alg_bytes_per_launch": alg, "avg_launch_us": dur * 1e6}
+        result["roofline"] = lunar_roofline(n, ev_ms * 1e-3 / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and (args.workload in ALG_BYTES or args.workload == "lunar_lander"):
         result["cpu_baseline"] = cpu_baseline(args.workload, n, args.seed)
 
@@ -344,10 +379,10 @@ def main():
         # headline region (never part of `value`).  Every rank reaches both collectives even if its run raised.
         msteps, mwarm, m_el, m_err = 64, 320, -1.0, None
         try:
-            mpop, mst, mbase = mg.mixed_population(1 << 20), [], 0
-            for name, cnt in mpop.items():
-                mst.append(Stepper(mg, torch, name, cnt, local_rank, args.seed + 3, mbase + rank * cnt, stream, "fused", args.launch))
-                mbase += world * cnt
+            mplan = mg.population_plan("mixed", world, rank, "weak", n_per_gpu=1 << 20)
+            mstreams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in mplan[1:]]   # the three families overlap on the device
+            mst = [Stepper(mg, torch, name, cnt, local_rank, args.seed + 3, gbase, st_, "fused", args.launch)
+                   for (name, cnt, gbase), st_ in zip(mplan, mstreams)]
             for st in mst:
                 st.run(mwarm)          # LunarLander needs a few hundred steps to reach its steady contact mix
             for st in mst:
@@ -375,7 +410,7 @@ def main():
         if m_el > 0:
             mixed_rec = {"env_steps_per_s": (1 << 20) * world * msteps / m_el, "ms_per_step": 1e3 * m_el / msteps,
                          "n_envs_total": (1 << 20) * world, "n_gpus": world, "steps": msteps, "warmup": mwarm,
-                         "per_gpu": "524288 CartPole + 262144 MountainCar + 262144 LunarLander (wind on), fused auto-reset",
+                         "per_gpu": "524288 CartPole + 262144 MountainCar + 262144 LunarLander (wind on), fused auto-reset, one stream per family",
                          "scaling": "weak", "note": "max over ranks, barrier before; LunarLander dominates the step time"}
         else:
             mixed_rec = {"error": m_err or "failed on another rank"}
@@ -398,6 +433,8 @@ def main():
             if wl in ALG_BYTES:
                 rec["alg_GBps"] = ALG_BYTES[wl] * cnt * k / (ms * 1e-3) / 1e9
                 rec["hbm_frac"] = rec["alg_GBps"] * 1e9 / HBM_PEAK
+            if wl == "lunar_lander":
+                rec["roofline"] = lunar_roofline(cnt, ms * 1e-3 / k)
             extra[name] = rec
             st.close()
         # fused K-step rollout (mgym_rollout): same semantics as K steps, state stays in registers
@@ -443,6 +480,33 @@ def main():
     if mixed_rec is not None and rank == 0:
         result.setdefault("extra", {})["mixed_configs4_this_n"] = mixed_rec
 
+    if dist is not None and args.workload in ("cartpole", "mixed") and not args.no_extra:
+        # the optional collective: all-gather of the CartPole observation shards into a learner tensor on every
+        # rank, RCCL over xGMI; off the step path, reported on its own (rehearsable on one GPU with MGYM_FORCE_DIST=1)
+        from modurl_gym_amd.shard import all_gather_observations, all_reduce_episode_count
+        from modurl_gym_amd.torch_env import _DeviceSpan
+        ag = None
+        try:
+            ptr, stride = lead.env.observation_device()
+            with torch.cuda.stream(stream):
+                view = torch.as_tensor(_DeviceSpan(ptr, (4, lead.n), (4 * stride, 4), lead), device=f"cuda:{local_rank}")
+                for _ in range(3):
+                    all_gather_observations(view, world)
+                torch.cuda.synchronize()
+                t0g = time.perf_counter()
+                for _ in range(20):
+                    all_gather_observations(view, world)
+                torch.cuda.synchronize()
+                ag = (time.perf_counter() - t0g) / 20
+            episodes = all_reduce_episode_count(lead.env.episode_count(), device=f"cuda:{local_rank}")
+        except Exception as e:  # noqa: BLE001
+            ag, episodes = None, repr(e)
+        if rank == 0:
+            result.setdefault("extra", {})["all_gather_observations"] = {
+                "ms": None if ag is None else ag * 1e3, "bytes_per_rank": lead.n * 16, "world": world,
+                "episodes_finished_all_ranks": episodes,
+                "note": "torch.distributed all_gather (nccl = RCCL) of the [4][n] CartPole observation shard + 8-byte all-reduce of the "
+                        "finished-episode counters; never inside the timed region"}
     for s in steppers:
         s.close()
     if dist is not None:

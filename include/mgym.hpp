@@ -58,6 +58,16 @@ class VecGym {
         check(mgym_step(env_, actions, obs_out, reward, done, trunc));
     }
     void sync() { check(mgym_sync(env_)); }
+    // K fused steps under the on-device uniform random policy (CartPole); actions_out may be null
+    void rollout_uniform(uint64_t policy_seed, int K, void* actions_out, float* obs, float* reward, uint8_t* done, uint8_t* trunc) {
+        check(mgym_rollout_uniform(env_, policy_seed, K, actions_out, obs, reward, done, trunc));
+    }
+    // env-steps that returned done or truncated since creation (synchronises)
+    uint64_t episode_count() {
+        uint64_t c = 0;
+        check(mgym_episode_count(env_, &c));
+        return c;
+    }
     const float* observation(uint64_t* col_stride) {
         const float* p = nullptr;
         check(mgym_observation(env_, &p, col_stride));
@@ -77,6 +87,14 @@ class VecGym {
 // single environment with the reference's scalar signature (n_envs = 1)
 class SingleGym {
   public:
+    // owns five device allocations and a handle: not copyable (a copy would free them twice), movable
+    SingleGym(const SingleGym&) = delete;
+    SingleGym& operator=(const SingleGym&) = delete;
+    SingleGym(SingleGym&& o) noexcept
+        : vec_(o.vec_), d_act_(o.d_act_), d_obs_(o.d_obs_), d_rew_(o.d_rew_), d_done_(o.d_done_), d_trunc_(o.d_trunc_) {
+        o.vec_ = nullptr; o.d_act_ = nullptr; o.d_obs_ = nullptr; o.d_rew_ = nullptr; o.d_done_ = nullptr; o.d_trunc_ = nullptr;
+    }
+    SingleGym& operator=(SingleGym&&) = delete;
     std::vector<float> reset() {
         vec_->reset(nullptr, d_obs_);
         vec_->sync();
@@ -96,6 +114,7 @@ class SingleGym {
         check(mgym_malloc(dev, 16, &p)); d_trunc_ = static_cast<uint8_t*>(p);
     }
     ~SingleGym() {
+        if (!vec_) return;  // moved from
         const int dev = vec_->device();
         mgym_free(dev, d_act_); mgym_free(dev, d_obs_); mgym_free(dev, d_rew_); mgym_free(dev, d_done_); mgym_free(dev, d_trunc_);
         delete vec_;

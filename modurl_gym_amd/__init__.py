@@ -8,9 +8,9 @@ from ._lib import (CARTPOLE, LUNARLANDER, MOUNTAINCAR, MOUNTAINCAR_CONT, LIB_PAT
 from .envs import (BadConfigError, CartPoleV1, DeviceArray, InvalidActionError, LunarLanderV3,  # noqa: F401
                    MgymError, MountainCarContinuousV0, MountainCarV0, NotResetError, StepInfo, VecEnv,
                    device_count, get_spec)
-from .shard import Shard, mixed_population, shard_range  # noqa: F401
+from .shard import Shard, all_reduce_episode_count, mixed_population, population_plan, shard_range  # noqa: F401
 from .torch_env import TorchVecEnv  # noqa: F401
 
 __all__ = ["CartPoleV1", "MountainCarV0", "MountainCarContinuousV0", "LunarLanderV3", "VecEnv", "StepInfo",
            "DeviceArray", "MgymError", "InvalidActionError", "NotResetError", "BadConfigError", "device_count",
-           "get_spec", "shard_range", "mixed_population", "Shard", "TorchVecEnv"]
+           "get_spec", "shard_range", "mixed_population", "population_plan", "all_reduce_episode_count", "Shard", "TorchVecEnv"]

@@ -142,6 +142,30 @@ impl VecGym {
         check(unsafe { mgym_rollout(self.env, actions, k, obs, reward, done, truncated) })
     }
 
+    /// K fused steps under the on-device uniform random policy (CartPole; `mgym_rollout_uniform`): no action table.
+    /// `actions_out` (`[K][n]` u32, may be null) receives the drawn actions.
+    #[allow(clippy::too_many_arguments)]
+    pub fn rollout_uniform(
+        &mut self,
+        policy_seed: u64,
+        k: i32,
+        actions_out: *mut c_void,
+        obs: *mut f32,
+        reward: *mut f32,
+        done: *mut u8,
+        truncated: *mut u8,
+    ) -> Result<(), MgymError> {
+        check(unsafe { mgym_rollout_uniform(self.env, policy_seed, k, actions_out, obs, reward, done, truncated) })
+    }
+
+    /// Env-steps that returned `done` or `truncated` since creation (ballot/popcount reduction inside the step
+    /// kernels); synchronises the stream.
+    pub fn episode_count(&mut self) -> Result<u64, MgymError> {
+        let mut c = 0u64;
+        check(unsafe { mgym_episode_count(self.env, &mut c) })?;
+        Ok(c)
+    }
+
     /// Zero-copy view of the engine-owned observation columns: (pointer, column stride in floats).
     pub fn observation(&self) -> Result<(*const f32, u64), MgymError> {
         let (mut p, mut stride) = (std::ptr::null(), 0u64);

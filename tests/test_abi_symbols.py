@@ -84,3 +84,35 @@ def test_rust_ffi_declarations_cover_the_header():
     for name, val in re.findall(r"(MGYM_[A-Z_]+) = (\d+)", header):
         m = re.search(r"pub const %s: [a-z_0-9]+ = (\d+);" % name, sys_rs)
         assert m and m.group(1) == val, name
+
+
+def test_rust_shim_has_the_reference_builder_surface():
+    """The reference is constructed as `CartPoleV1::builder().sutton_barto_reward(..).is_euler(..).build()` /
+    `::default()` (cartpole.rs:34-44,228-231), `MountainCarV0::builder()` (mountain_car.rs:25-34) and
+    `LunarLanderV3::builder()` with `seed: Option<u64>` (lunar_lander.rs:278-291).  The shim cannot be compiled here
+    (no rustc), so check its source for the same `#[bon] #[builder]` constructors, argument names, defaults, the gravity
+    assert message and `impl Default`."""
+    src = open(os.path.join(ROOT, "rust", "modurl_gym_mgym", "src", "lib.rs")).read()
+    cargo = open(os.path.join(ROOT, "rust", "modurl_gym_mgym", "Cargo.toml")).read()
+    assert re.search(r'^bon = "3', cargo, re.M)
+    expect = {
+        "CartPoleV1": [("device", "&Device", "&Device::Cpu"), ("sutton_barto_reward", "bool", "false"), ("is_euler", "bool", "true")],
+        "MountainCarV0": [("device", "&Device", "&Device::Cpu"), ("goal_velocity", "f32", "0.0")],
+        "LunarLanderV3": [("gravity", "f32", "-10.0"), ("enable_wind", "bool", "false"), ("wind_power", "f32", "15.0"),
+                          ("turbulence_power", "f32", "1.5"), ("device", "Device", "Device::Cpu")],
+    }
+    for name, args in expect.items():
+        m = re.search(r"#\[bon\]\s*impl %s \{(.*?)\n\}" % name, src, re.S)
+        assert m, name
+        body = m.group(1)
+        assert "#[builder]" in body and "pub fn new(" in body
+        for arg, ty, default in args:
+            assert re.search(r"#\[builder\(default = %s\)\]\s*%s: %s," % (re.escape(default), arg, re.escape(ty)), body), (name, arg)
+        assert re.search(r"impl Default for %s \{\s*fn default\(\) -> Self \{\s*%s::builder\(\)\.build\(\)" % (name, name), src), name
+        assert re.search(r"seed: Option<u64>,", body), name
+    assert '"gravity (current value: {}) must be between -12 and 0"' in src          # lunar_lander.rs:292-296
+    assert "-12.0 < gravity && gravity < 0.0" in src
+    # the reference's own unit tests construct the envs like this (cartpole.rs:366, lunar_lander.rs:1596,1693)
+    for call in ("CartPoleV1::builder().build()", "CartPoleV1::default()", "MountainCarV0::builder().build()",
+                 "LunarLanderV3::builder().enable_wind(true).seed(42).build()"):
+        assert call in src, call
