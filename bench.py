@@ -242,6 +242,11 @@ def cpu_baseline(workload, n, seed):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Native libraries print banners there (RCCL's version block at communicator
+    # creation): point fd 1 at stderr for the run and keep the real stdout for the result line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -513,7 +518,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t cartpole_wave_step(const CartPoleDev& d, Car
     constexpr CartPoleParams P = cartpole_params(EULER ? 1 : 0, SB ? 1 : 0);
     bool ok = true;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) ok = ok && cartpole_fast_ok(s[k].th, s[k].thd, a[k]);
+    for (int k = 0; k < VEC; ++k) ok = ok & cartpole_fast_ok(s[k].th, s[k].thd, a[k]);  // bitwise: no short-circuit branches
     if (__all(ok)) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) cartpole_step_fast<EULER, SB>(P, s[k].x, s[k].xd, s[k].th, s[k].thd, s[k].ctr, a[k], r[k], dn[k], tr[k]);
@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t cartpole_wave_step(const CartPoleDev& d, Car
 __device__ __forceinline__ void cartpole_flush_counts(const CartPoleDev& d, uint32_t finished, bool bad) {
     // one fire-and-forget atomic per wave, spread over kDoneShards addresses; the (rare) error bit likewise
     if ((threadIdx.x & 63) == 0 && finished)
-        atomicAdd(d.done_count + ((blockIdx.x * kWaves + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+        atomicAdd(d.done_count + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
     if (__any(bad)) {
         if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
     }
@@ -172,18 +172,21 @@ template <typename T> __device__ __forceinline__ T* at(void* base, uint32_t byte
 
 // VEC: envs per lane (4 = 16-byte accesses; 1 = fallback for misaligned caller buffers).
 // RESET: MGYM_FLAG_AUTO_RESET.  NT: non-temporal stores for the output columns.
-template <int VEC, bool EULER, bool SB, bool RESET, bool NT>
-__global__ void __launch_bounds__(kBlock)
+template <int VEC, bool EULER, bool SB, bool RESET, bool NT, int BLK>
+__global__ void __launch_bounds__(BLK)
 cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __restrict__ obs_out,
                      float* __restrict__ rew, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ WaveResetScratch<VEC> lds_[RESET ? kWaves : 1];
-    constexpr uint64_t kPerBlock = (uint64_t)kBlock * VEC;
+    __shared__ WaveResetScratch<VEC> lds_[RESET ? BLK / 64 : 1];
+    constexpr uint64_t kPerBlock = (uint64_t)BLK * VEC;
     bool bad = false;
     uint32_t finished = 0;
     WaveResetScratch<VEC>& lds = lds_[RESET ? (threadIdx.x >> 6) : 0];
     const uint32_t lane_env = threadIdx.x * VEC;     // first env of this lane within the block's slice
     const uint32_t off4 = lane_env * 4u;             // its byte offset in a 4-byte column
     const uint64_t col = d.n_pad;                    // engine column stride (words)
+    const uint32_t colb = (uint32_t)col * 4u;        // ... in bytes
+    // raw buffer resource over the engine's allocation (stride 0, no bounds clamp, 32-bit data format: gfx9 word 3 = 0x00020000)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.base, 0, 0xffffffff, 0x00020000);
     for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {  // wave-uniform
         // uniform (scalar) bases of this block pass
         float* const bx = d.base + base;
@@ -197,23 +200,29 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
         uint32_t dn[VEC], tr[VEC];
         const bool in = lane_env < rem;  // the host launches VEC = 4 only when n % 4 == 0: a lane is wholly in or out
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { valid[k] = in; s[k] = {0.f, 0.f, 0.f, 0.f, 0u}; a[k] = 0u; }
-        if (in) {
-            if (VEC == 4) {
-                // engine columns are padded to n_pad, caller buffers were checked for 16-B alignment.
-                // theta, theta_dot and the action first: the sin/cos polynomial can start while x, x_dot, ctr are in flight
-                float4 vth = *at<float4>(bx + 2 * col, off4);
-                float4 vthd = *at<float4>(bx + 3 * col, off4);
-                uint4 va = *at<uint4>(ba, off4);
-                float4 vx = *at<float4>(bx, off4);
-                float4 vxd = *at<float4>(bx + col, off4);
-                uint4 vc = *at<uint4>(bx + 4 * col, off4);
-                s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x};
-                s[1 % VEC] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
-                s[2 % VEC] = {vx.z, vxd.z, vth.z, vthd.z, vc.z};
-                s[3 % VEC] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
-                a[0] = va.x; a[1 % VEC] = va.y; a[2 % VEC] = va.z; a[3 % VEC] = va.w;
-            } else {
+        for (int k = 0; k < VEC; ++k) valid[k] = in;
+        const uint32_t sb = (uint32_t)base * 4u;  // byte offset of this pass in a column (n <= 2^27: every offset < 2^32)
+        if (VEC == 4) {
+            // Engine columns: buffer loads — resource descriptor and column/pass offsets in SGPRs, one constant VGPR lane
+            // offset, no per-lane address arithmetic.  The columns are padded to n_pad (a multiple of the block's 1024
+            // envs), so every lane of the block may load (padding holds zeros and is never stored back).
+            // theta, theta_dot and the action first: the sin/cos polynomial can start while x, x_dot, ctr are in flight.
+            const u32x4 vth = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 2u * colb, 0);
+            const u32x4 vthd = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 3u * colb, 0);
+            uint4 va = make_uint4(0u, 0u, 0u, 0u);
+            if (in) va = *at<uint4>(ba, off4);  // caller buffer: n words exactly
+            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb, 0);
+            const u32x4 vxd = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + colb, 0);
+            const u32x4 vc = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 4u * colb, 0);
+            s[0] = {as_f32(vx.x), as_f32(vxd.x), as_f32(vth.x), as_f32(vthd.x), vc.x};
+            s[1 % VEC] = {as_f32(vx.y), as_f32(vxd.y), as_f32(vth.y), as_f32(vthd.y), vc.y};
+            s[2 % VEC] = {as_f32(vx.z), as_f32(vxd.z), as_f32(vth.z), as_f32(vthd.z), vc.z};
+            s[3 % VEC] = {as_f32(vx.w), as_f32(vxd.w), as_f32(vth.w), as_f32(vthd.w), vc.w};
+            a[0] = va.x; a[1 % VEC] = va.y; a[2 % VEC] = va.z; a[3 % VEC] = va.w;
+        } else {
+            s[0] = {0.f, 0.f, 0.f, 0.f, 0u};
+            a[0] = 0u;
+            if (in) {
                 s[0] = {*at<float>(bx, off4), *at<float>(bx + col, off4), *at<float>(bx + 2 * col, off4), *at<float>(bx + 3 * col, off4),
                         *at<uint32_t>(bx + 4 * col, off4)};
                 a[0] = *at<uint32_t>(ba, off4);
@@ -224,11 +233,12 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
 
         if (in) {
             if (VEC == 4) {
-                st4<NT>(at<float>(bx, off4), s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
-                st4<NT>(at<float>(bx + col, off4), s[0].xd, s[1 % VEC].xd, s[2 % VEC].xd, s[3 % VEC].xd);
-                st4<NT>(at<float>(bx + 2 * col, off4), s[0].th, s[1 % VEC].th, s[2 % VEC].th, s[3 % VEC].th);
-                st4<NT>(at<float>(bx + 3 * col, off4), s[0].thd, s[1 % VEC].thd, s[2 % VEC].thd, s[3 % VEC].thd);
-                st4u<NT>(at<uint32_t>(bx + 4 * col, off4), s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr);
+                constexpr int kAux = NT ? 2 : 0;  // cache-policy bits of the buffer store: 2 = nt
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].x), as_u32(s[1 % VEC].x), as_u32(s[2 % VEC].x), as_u32(s[3 % VEC].x)}, rs, off4, sb, kAux);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].xd), as_u32(s[1 % VEC].xd), as_u32(s[2 % VEC].xd), as_u32(s[3 % VEC].xd)}, rs, off4, sb + colb, kAux);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].th), as_u32(s[1 % VEC].th), as_u32(s[2 % VEC].th), as_u32(s[3 % VEC].th)}, rs, off4, sb + 2u * colb, kAux);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].thd), as_u32(s[1 % VEC].thd), as_u32(s[2 % VEC].thd), as_u32(s[3 % VEC].thd)}, rs, off4, sb + 3u * colb, kAux);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s[0].ctr, s[1 % VEC].ctr, s[2 % VEC].ctr, s[3 % VEC].ctr}, rs, off4, sb + 4u * colb, kAux);
                 if (obs_out) {
                     float* const bo = obs_out + base;
                     *at<float4>(bo, off4) = make_float4(s[0].x, s[1 % VEC].x, s[2 % VEC].x, s[3 % VEC].x);
@@ -408,6 +418,7 @@ struct CartPoleEnv final : Env {
     void* base = nullptr;
     CartPoleDev dev{};
     bool auto_reset = false;
+    int step_block = getenv("MGYM_CARTPOLE_BLOCK") ? atoi(getenv("MGYM_CARTPOLE_BLOCK")) : kBlock;  // threads per block of the step kernel (tuning knob)
     uint32_t policy_calls = 0;  // mgym_rollout_uniform calls so far (Philox counter word of the policy stream)
 
     ~CartPoleEnv() override {
@@ -417,6 +428,10 @@ struct CartPoleEnv final : Env {
     int init() override {
         obs_dim = 4;
         state_cols = 7;
+        if (n > (1ull << 27)) {  // the step kernel addresses the five columns with 32-bit byte offsets from one buffer resource
+            set_last_error("mgym_create: a CartPole handle holds at most 134 217 728 environments (shard larger populations over handles)");
+            return MGYM_ERR_BAD_ARG;
+        }
         MGYM_HIP(hipMalloc(&base, 5 * n_pad * sizeof(float)));
         MGYM_HIP(hipMemsetAsync(base, 0, 5 * n_pad * sizeof(float), stream));
         dev.base = static_cast<float*>(base);
@@ -449,16 +464,24 @@ struct CartPoleEnv final : Env {
         return MGYM_OK;
     }
 
-    template <int VEC, bool RESET>
-    void launch_step(dim3 g, const uint32_t* act, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) {
+    template <int VEC, bool RESET, int BLK>
+    void launch_step_blk(const uint32_t* act, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) {
         const bool eu = cfg.is_euler, sb = cfg.sutton_barto_reward;
-        dim3 b(kBlock);
-#define MGYM_CP_LAUNCH(E, S) hipLaunchKernelGGL((cartpole_step_kernel<VEC, E, S, RESET, kNtStores>), g, b, 0, stream, dev, act, obs_out, reward, done, trunc)
+        uint64_t nb = (n + (uint64_t)BLK * VEC - 1) / ((uint64_t)BLK * VEC);
+        const uint64_t cap = (uint64_t)kMaxBlocks * kBlock / BLK;   // same thread count as the kBlock-sized cap
+        dim3 g((unsigned)(nb > cap ? cap : (nb ? nb : 1))), b(BLK);
+#define MGYM_CP_LAUNCH(E, S) hipLaunchKernelGGL((cartpole_step_kernel<VEC, E, S, RESET, kNtStores, BLK>), g, b, 0, stream, dev, act, obs_out, reward, done, trunc)
         if (eu && !sb) MGYM_CP_LAUNCH(true, false);
         else if (eu) MGYM_CP_LAUNCH(true, true);
         else if (!sb) MGYM_CP_LAUNCH(false, false);
         else MGYM_CP_LAUNCH(false, true);
 #undef MGYM_CP_LAUNCH
+    }
+    template <int VEC, bool RESET>
+    void launch_step(dim3, const uint32_t* act, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) {
+        if (VEC == 4 && step_block == 64) launch_step_blk<VEC, RESET, 64>(act, obs_out, reward, done, trunc);
+        else if (VEC == 4 && step_block == 128) launch_step_blk<VEC, RESET, 128>(act, obs_out, reward, done, trunc);
+        else launch_step_blk<VEC, RESET, kBlock>(act, obs_out, reward, done, trunc);
     }
 
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
