@@ -199,7 +199,8 @@ int mgym_timer_stop(mgym_env *env, float *elapsed_ms); /* synchronises */
 
 /* Test seam: evaluates, on the device, the exhaustive bit-identity checks of the cheap CartPole instruction sequences
  * against the reference-form arithmetic (cartpole.rs:264-271 with IEEE divide and glibc-equal sin/cos); see
- * modurl_gym_amd/csrc/selftest.hip.  mismatches[4] = {sincos, x / total_mass, n / d, whole step}; all must be 0. */
+ * modurl_gym_amd/csrc/selftest.hip.  mismatches[5] = {CartPole sincos, x / total_mass, n / d, whole CartPole step, fused lock-step
+ * sincos / cos of the LunarLander and MountainCar kernels}; all must be 0. */
 int mgym_selftest_cartpole_math(int device, uint64_t *mismatches);
 
 /* hipGraph capture of a caller-issued launch sequence on the env's stream. */

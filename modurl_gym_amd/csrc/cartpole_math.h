@@ -17,8 +17,6 @@
 
 namespace mgym {
 
-MG_HD float cp_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-MG_HD double cp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 MG_HD float cp_copysign(float mag, float sgn) { return as_f32((as_u32(mag) & 0x7fffffffu) | (as_u32(sgn) & 0x80000000u)); }
 
 

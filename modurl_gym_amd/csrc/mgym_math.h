@@ -45,6 +45,10 @@ MG_HD float as_f32(uint32_t u) {
 #endif
 }
 
+// explicit fused multiply-add (the only contraction in the code base: -ffp-contract=off keeps everything else unfused)
+MG_HD float cp_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MG_HD double cp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // ---- sincosf polynomial tables (table[1] has the cosine signs flipped) ----
 struct SinCosTab {
     double c0, c1, c2, c3, c4;  // cosine polynomial
@@ -209,6 +213,11 @@ MG_HD void mg_sincosf(float y, float* sp, float* cp) {
 // tests/test_math_host.py checks it bit-for-bit against mg_sincosf over the floats.
 MG_HD void mg_sincosf_u(float y, float* sp, float* cp) {
     if (abstop12(y) < abstop12(120.0f)) {
+        // The two polynomials are evaluated with each  a + b*c  pair fused (12 f64 operations instead of 19).  The fused
+        // values differ from the individually rounded ones by < 2^-52 relative, which would change the f32 rounding of the
+        // result only within that distance of a rounding boundary: enumerating every f32 with |y| < 120 shows that this
+        // happens for none of them (tests/native/cartpole_fast_check.cpp, group sincos_u; mgym_selftest_cartpole_math
+        // repeats the enumeration on the GPU).  The range reduction stays unfused.
         int n;
         const double xr = reduce_fast((double)y, &n);
         const double x2 = xr * xr;
@@ -217,16 +226,16 @@ MG_HD void mg_sincosf_u(float y, float* sp, float* cp) {
         const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
                      c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
         const double x3 = xs * x2;
-        const double ts = s2 + x2 * s3;
+        const double ts = cp_fma(x2, s3, s2);
         const double x7 = x3 * x2;
-        const double sv = xs + x3 * s1;
-        const float sinv = (float)(sv + x7 * ts);
+        const double sv = cp_fma(x3, s1, xs);
+        const float sinv = (float)cp_fma(x7, ts, sv);
         const double x4 = x2 * x2;
-        const double t2 = c3 + x2 * c4;
-        const double t1 = c0 + x2 * c1;
+        const double t2 = cp_fma(x2, c4, c3);
+        const double t1 = cp_fma(x2, c1, c0);
         const double x6 = x4 * x2;
-        const double cv = t1 + x4 * c2;
-        const double cr = cv + x6 * t2;
+        const double cv = cp_fma(x4, c2, t1);
+        const double cr = cp_fma(x6, t2, cv);
         const float cosv = (float)((n & 2) ? -cr : cr);
         const bool tiny = abstop12(y) < abstop12(0x1p-12f);
         const bool odd = (n & 1) != 0;
@@ -235,6 +244,36 @@ MG_HD void mg_sincosf_u(float y, float* sp, float* cp) {
         return;
     }
     mg_sincosf_reduced(y, sp, cp);
+}
+
+// cosine alone, lock-step and fused like mg_sincosf_u (MountainCar: cos(3 * position), mountain_car.rs:302; the positions
+// of a wave spread over several quadrants, so the branchy mg_cosf runs every path).  Bit-identical to mg_cosf for every
+// f32 (|y| < 120 by the same enumeration; beyond, it IS mg_cosf's out-of-line path).
+MG_HD float mg_cosf_u(float y) {
+    if (abstop12(y) < abstop12(120.0f)) {
+        int n;
+        const double xr = reduce_fast((double)y, &n);
+        const double x2 = xr * xr;
+        const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
+                     c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+        const double x3 = xr * x2;
+        const double ts = cp_fma(x2, s3, s2);
+        const double x7 = x3 * x2;
+        const double sv = cp_fma(x3, s1, xr);
+        const double sinv = cp_fma(x7, ts, sv);
+        const double x4 = x2 * x2;
+        const double t2 = cp_fma(x2, c4, c3);
+        const double t1 = cp_fma(x2, c1, c0);
+        const double x6 = x4 * x2;
+        const double cv = cp_fma(x4, c2, t1);
+        const double cosv = cp_fma(x6, t2, cv);
+        const int q = n & 3;  // cos(y) = {cos, -sin, -cos, sin}[q](xr)
+        double r = (q & 1) ? sinv : cosv;
+        r = (q == 1 || q == 2) ? -r : r;
+        return (float)r;
+    }
+    return mg_sincosf_large(y, 1);
 }
 
 // ---- expm1f / tanhf: fdlibm (Sun Microsystems) float versions as shipped by glibc ----

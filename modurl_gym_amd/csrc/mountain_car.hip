@@ -74,7 +74,7 @@ __device__ __forceinline__ void mountaincar_step_one(const MountainCarParams& p,
         if (action_bits >= 3u) { bad = true; reward = 0.0f; done = 0u; return; }  // :294
         push = ((float)action_bits - 1.0f) * p.force;                               // :301
     }
-    velocity += push + mg_cosf(3.0f * position) * (-p.gravity);                     // :301-302
+    velocity += push + mg_cosf_u(3.0f * position) * (-p.gravity);                     // :301-302
     velocity = clampf(velocity, -p.max_speed, p.max_speed);                         // :304
     position += velocity;                                                           // :306
     position = clampf(position, p.min_position, p.max_position);                    // :308
@@ -157,6 +157,69 @@ mountaincar_step_kernel(MountainCarDev d, const uint32_t* __restrict__ act, floa
         }
     }
     mountaincar_flush_counts(d, finished, bad);
+}
+
+// The 16-byte path (caller buffers aligned, n % 4 == 0): one lane owns 4 consecutive environments; block-uniform passes;
+// engine columns through one buffer resource (descriptor and column / pass offsets in SGPRs, one constant VGPR lane
+// offset: no per-lane address arithmetic; n <= 2^27 so every byte offset fits 32 bits); the columns are padded to n_pad
+// (a multiple of the block's 1024 envs), so every lane may load them — only in-range lanes store.  The done mask is
+// reduced with __ballot + popcount for mgym_episode_count; resets are rare here (episodes last >= 100 steps) and stay
+// in place.
+typedef uint32_t mc_u32x4v __attribute__((ext_vector_type(4)));
+template <bool CONT, bool RESET>
+__global__ void __launch_bounds__(kBlock)
+mountaincar_step4_kernel(MountainCarDev d, const uint32_t* __restrict__ act, float* __restrict__ obs_out,
+                         float* __restrict__ rew, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    constexpr uint64_t kPerBlock = (uint64_t)kBlock * 4;
+    const uint32_t lane_env = threadIdx.x * 4u, off4 = lane_env * 4u;
+    const uint32_t colb = (uint32_t)(d.vel - d.pos) * 4u;  // column stride in bytes
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.pos, 0, 0xffffffff, 0x00020000);
+    bool bad = false;
+    uint32_t finished = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {  // block-uniform
+        const uint64_t left = d.n - base;
+        const uint32_t rem = left < kPerBlock ? (uint32_t)left : (uint32_t)kPerBlock;
+        const bool in = lane_env < rem;
+        const uint32_t sb = (uint32_t)base * 4u;
+        const mc_u32x4v vp = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb, 0);
+        const mc_u32x4v vv = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + colb, 0);
+        uint4 va = CONT ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(1u, 1u, 1u, 1u);
+        if (in) va = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(act + base) + off4);
+        float ps[4] = {as_f32(vp.x), as_f32(vp.y), as_f32(vp.z), as_f32(vp.w)}, vs[4] = {as_f32(vv.x), as_f32(vv.y), as_f32(vv.z), as_f32(vv.w)}, r[4];
+        uint32_t a[4] = {va.x, va.y, va.z, va.w}, dn[4];
+        uint32_t any_done = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mountaincar_step_one<CONT>(d.p, ps[k], vs[k], a[k], r[k], dn[k], bad);
+            any_done |= dn[k];
+        }
+        const unsigned long long m = __ballot(in && any_done);
+        if (m) {  // rare: count and (RESET) restart the finished envs in place
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                finished += (uint32_t)__popcll(__ballot(in && dn[k]));
+                if (RESET && in && dn[k]) mountaincar_reset_one(d, base + lane_env + k, ps[k], vs[k]);
+            }
+        }
+        if (in) {
+            __builtin_amdgcn_raw_buffer_store_b128(mc_u32x4v{as_u32(ps[0]), as_u32(ps[1]), as_u32(ps[2]), as_u32(ps[3])}, rs, off4, sb, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(mc_u32x4v{as_u32(vs[0]), as_u32(vs[1]), as_u32(vs[2]), as_u32(vs[3])}, rs, off4, sb + colb, 2);
+            if (obs_out) {
+                float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(obs_out + base) + off4);
+                nt_store4(o, make_float4(ps[0], ps[1], ps[2], ps[3]));
+                nt_store4(o + d.n, make_float4(vs[0], vs[1], vs[2], vs[3]));
+            }
+            if (rew) nt_store4(reinterpret_cast<float*>(reinterpret_cast<char*>(rew + base) + off4), make_float4(r[0], r[1], r[2], r[3]));
+            if (done_out)
+                __builtin_nontemporal_store(dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24), reinterpret_cast<uint32_t*>(done_out + base + lane_env));
+            if (trunc_out) __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(trunc_out + base + lane_env));  // :328 truncated: false, always
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && finished)
+        atomicAdd(d.done_count + ((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_INVALID_ACTION);
+    }
 }
 
 // Fused K-step rollout (mgym_rollout): 4 environments per lane stay in registers for K steps; per step one 16-B
@@ -262,6 +325,7 @@ struct MountainCarEnv final : Env {
         if (base) (void)hipFree(base);
     }
 
+    bool use_step4 = !getenv("MGYM_MC_OLD_KERNEL");  // A/B knob: the per-thread grid-stride kernel of round 1
     int init() override {
         obs_dim = 2;
         state_cols = 3;
@@ -303,6 +367,15 @@ struct MountainCarEnv final : Env {
         bool vec_ok = aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) &&
                       (obs_out == nullptr || (aligned(obs_out, 16) && n % 4 == 0));
         dim3 gv(grid_for((n + 3) / 4)), gs(grid_for(n)), b(kBlock);
+        if (vec_ok && n % 4 == 0 && n <= (1ull << 27) && use_step4) {  // the structured 16-byte kernel
+            const bool rs = dev.auto_reset;
+            if (continuous) { if (rs) hipLaunchKernelGGL((mountaincar_step4_kernel<true, true>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+                              else hipLaunchKernelGGL((mountaincar_step4_kernel<true, false>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc); }
+            else { if (rs) hipLaunchKernelGGL((mountaincar_step4_kernel<false, true>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
+                   else hipLaunchKernelGGL((mountaincar_step4_kernel<false, false>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc); }
+            MGYM_HIP(hipGetLastError());
+            return MGYM_OK;
+        }
         if (continuous) {
             if (vec_ok) hipLaunchKernelGGL((mountaincar_step_kernel<4, true>), gv, b, 0, stream, dev, act, obs_out, reward, done, trunc);
             else hipLaunchKernelGGL((mountaincar_step_kernel<1, true>), gs, b, 0, stream, dev, act, obs_out, reward, done, trunc);

@@ -5,6 +5,8 @@
 //   out[1] divc   : every f32 in the proven range               cp_div_const(x, 1.1f) == x / 1.1f  (IEEE v_div_* sequence)
 //   out[2] div    : every f32 cos value c in [0, 1] -> divisor d, 32 numerators each (random + hard cases)
 //   out[3] step   : 2^28 random guard-admitted states, all four <EULER, SB> variants: fast form == reference form
+//   out[4] sincos_u : every f32 with |y| < 120, both signs: the fused lock-step mg_sincosf_u / mg_cosf_u (LunarLander,
+//                   MountainCar) == mg_sincosf / mg_cosf
 // Exposed as mgym_selftest_cartpole_math() (test seam; seconds on an MI355X).
 #include "common.h"
 #include "cartpole_step.h"
@@ -33,6 +35,23 @@ __global__ void __launch_bounds__(256) selftest_sincos_kernel(unsigned long long
             mg_sincosf(y, &s0, &c0);
             cp_sincos_small(y, &s1, &c1);
             bad += (as_u32(s0) != as_u32(s1) || as_u32(c0) != as_u32(c1)) ? 1u : 0u;
+        }
+    }
+    st_flush(out, bad);
+}
+
+__global__ void __launch_bounds__(256) selftest_sincos_u_kernel(unsigned long long* out) {
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x42f00000ull; u += stride) {
+#pragma unroll
+        for (uint32_t sg = 0; sg < 2; ++sg) {
+            const float y = as_f32((uint32_t)u | (sg << 31));
+            float s0, c0, s1, c1;
+            mg_sincosf(y, &s0, &c0);
+            mg_sincosf_u(y, &s1, &c1);
+            const float c2 = mg_cosf_u(y);
+            bad += (as_u32(s0) != as_u32(s1) || as_u32(c0) != as_u32(c1) || as_u32(c2) != as_u32(c0)) ? 1u : 0u;
         }
     }
     st_flush(out, bad);
@@ -123,24 +142,25 @@ __global__ void __launch_bounds__(256) selftest_step_kernel(unsigned long long* 
 
 using namespace mgym;
 
-extern "C" int mgym_selftest_cartpole_math(int device, uint64_t* mismatches /* [4] */) {
+extern "C" int mgym_selftest_cartpole_math(int device, uint64_t* mismatches /* [5] */) {
     if (!mismatches) { set_last_error("mgym_selftest_cartpole_math: NULL"); return MGYM_ERR_BAD_ARG; }
     int prev = -1;
     (void)hipGetDevice(&prev);
     MGYM_HIP(hipSetDevice(device));
     unsigned long long* d = nullptr;
-    MGYM_HIP(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
-    MGYM_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
+    MGYM_HIP(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
+    MGYM_HIP(hipMemset(d, 0, 5 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(selftest_sincos_kernel, dim3(4096), dim3(256), 0, nullptr, d + 0);
     hipLaunchKernelGGL(selftest_divc_kernel, dim3(4096), dim3(256), 0, nullptr, d + 1);
     hipLaunchKernelGGL(selftest_div_kernel, dim3(4096), dim3(256), 0, nullptr, d + 2);
     hipLaunchKernelGGL(selftest_step_kernel, dim3(4096), dim3(256), 0, nullptr, d + 3, 160);
+    hipLaunchKernelGGL(selftest_sincos_u_kernel, dim3(4096), dim3(256), 0, nullptr, d + 4);
     hipError_t e = hipDeviceSynchronize();
-    unsigned long long h[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    unsigned long long h[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return hip_fail(e, "selftest", __FILE__, __LINE__);
-    for (int i = 0; i < 4; ++i) mismatches[i] = h[i];
+    for (int i = 0; i < 5; ++i) mismatches[i] = h[i];
     return MGYM_OK;
 }

@@ -1,6 +1,7 @@
 // Exhaustive host-side proof that the cheaper CartPole instruction sequences (modurl_gym_amd/csrc/cartpole_math.h)
 // are bit-identical to the reference-form arithmetic.  Built with -mfma (hardware fused multiply-add = the IEEE
 // operation the GPU executes) and run by tests/test_oracle_classic.py.  Usage: cartpole_fast_check <threads> [stride]
+//   sincos_u : every f32 with |y| < 120 (both signs): the fused lock-step mg_sincosf_u / mg_cosf_u == mg_sincosf / mg_cosf
 //   sincos : every f32 with |y| < 0.75 (both signs): cp_sincos_small == mg_sincosf                (2 x 0x3f400000 inputs)
 //   divc   : every f32 x in the proven range: cp_div_const(x, 1.1f) == x / 1.1f                   (2^32 inputs)
 //   div    : every divisor d the step can form (d = 0.5f*(4/3 - 0.1f*c*c/1.1f), c any f32 in [-1,1]) against
@@ -17,7 +18,7 @@
 #include "../../modurl_gym_amd/csrc/cartpole_step.h"
 using namespace mgym;
 
-static std::atomic<unsigned long> bad_sc{0}, n_sc{0}, bad_dc{0}, n_dc{0}, bad_dv{0}, n_dv{0}, n_div_d{0}, bad_st{0}, n_st{0};
+static std::atomic<unsigned long> bad_su{0}, n_su{0}, bad_sc{0}, n_sc{0}, bad_dc{0}, n_dc{0}, bad_dv{0}, n_dv{0}, n_div_d{0}, bad_st{0}, n_st{0};
 
 static uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s; }
 // a float with a uniformly drawn exponent in [lo_e, hi_e] (biased), random mantissa and sign
@@ -76,6 +77,25 @@ static void work(int tid, int nthreads, uint32_t stride) {
             }
             ++c_sc;
         }
+    }
+    // ---- fused lock-step sincos / cos of the LunarLander and MountainCar kernels: every f32 with |y| < 120 ----
+    {
+        unsigned long b_su = 0, c_su = 0;
+        for (uint64_t u = (uint64_t)tid * stride; u < 0x42f00000ull; u += (uint64_t)nthreads * stride) {
+            for (int sg = 0; sg < 2; ++sg) {
+                const float y = as_f32((uint32_t)u | ((uint32_t)sg << 31));
+                float s0, c0, s1, c1;
+                mg_sincosf(y, &s0, &c0);
+                mg_sincosf_u(y, &s1, &c1);
+                const float c2 = mg_cosf_u(y), c3 = mg_cosf(y);
+                if (as_u32(s0) != as_u32(s1) || as_u32(c0) != as_u32(c1) || as_u32(c2) != as_u32(c3) || as_u32(c3) != as_u32(c0)) {
+                    if (b_su < 4) fprintf(stderr, "sincos_u mismatch y=%a: ref (%a,%a) u (%a,%a) cos_u %a cos %a\n", y, s0, c0, s1, c1, c2, c3);
+                    ++b_su;
+                }
+                ++c_su;
+            }
+        }
+        bad_su += b_su; n_su += c_su;
     }
     // ---- x / total_mass ----
     const float M = 0.1f + 1.0f;  // cartpole.rs:48
@@ -146,9 +166,10 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t, nthreads, stride);
     for (auto& t : th) t.join();
+    printf("sincos_u checked=%lu mismatches=%lu\n", n_su.load(), bad_su.load());
     printf("sincos_small checked=%lu mismatches=%lu\n", n_sc.load(), bad_sc.load());
     printf("div_const checked=%lu mismatches=%lu\n", n_dc.load(), bad_dc.load());
     printf("div checked=%lu mismatches=%lu divisors=%lu\n", n_dv.load(), bad_dv.load(), n_div_d.load());
     printf("step checked=%lu mismatches=%lu\n", n_st.load(), bad_st.load());
-    return (bad_sc.load() || bad_dc.load() || bad_dv.load() || bad_st.load()) ? 1 : 0;
+    return (bad_su.load() || bad_sc.load() || bad_dc.load() || bad_dv.load() || bad_st.load()) ? 1 : 0;
 }

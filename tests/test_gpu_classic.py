@@ -509,9 +509,9 @@ def test_cartpole_fast_math_exhaustive_on_gpu():
     evaluated by gfx950 kernels (hardware v_rcp_f32 / fused multiply-add / IEEE divide): all four counts must be 0."""
     import ctypes as C
     from modurl_gym_amd import _lib
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 5)()
     assert _lib.load().mgym_selftest_cartpole_math(0, out) == _lib.OK
-    assert list(out) == [0, 0, 0, 0], f"mismatches (sincos, x/M, n/d, step) = {list(out)}"
+    assert list(out) == [0, 0, 0, 0, 0], f"mismatches (sincos, x/M, n/d, step, lock-step sincos/cos below 120) = {list(out)}"
 
 
 def test_episode_count_counts_finished_env_steps():

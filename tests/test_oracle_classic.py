@@ -219,5 +219,6 @@ def test_cartpole_fast_math_is_bit_identical_exhaustively():
     rows = {l.split()[0]: dict(kv.split("=") for kv in l.split()[1:]) for l in r.stdout.strip().splitlines()}
     assert int(rows["sincos_small"]["checked"]) == 2 * 0x3f400000 and int(rows["div_const"]["checked"]) > 3_000_000_000
     assert int(rows["div"]["checked"]) > 400_000_000 and int(rows["step"]["checked"]) > 50_000_000
-    for k in ("sincos_small", "div_const", "div", "step"):
+    assert int(rows["sincos_u"]["checked"]) == 2 * 0x42f00000   # every f32 below 120, both signs
+    for k in ("sincos_u", "sincos_small", "div_const", "div", "step"):
         assert int(rows[k]["mismatches"]) == 0, r.stdout
