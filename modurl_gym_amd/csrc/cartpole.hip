@@ -284,41 +284,50 @@ cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_
     bool bad = false;
     uint32_t finished = 0;
     WaveResetScratch<4>& lds = lds_[RESET ? (threadIdx.x >> 6) : 0];
+    // per-step buffers through buffer resources: descriptor + (step, pass) offset in SGPRs, one constant VGPR lane offset.
+    // The host wrapper guarantees K * n * 16 < 2^32 (every byte offset fits 32 bits) and n % 4 == 0.
+    const uint32_t lane_env = threadIdx.x * 4u, off4 = lane_env * 4u;
+    const uint32_t colb = (uint32_t)d.n_pad * 4u, nb4 = (uint32_t)d.n * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.base, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(POLICY == ROLL_TABLE ? act : act_out), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rew, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(done_out, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(trunc_out, 0, 0xffffffff, 0x00020000);
     for (uint64_t base = (uint64_t)blockIdx.x * kPerBlock; base < d.n; base += (uint64_t)gridDim.x * kPerBlock) {
         const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
-        const bool in = i0 < d.n;  // n % 4 == 0 is required by the host wrapper
+        const uint64_t left = d.n - base;
+        const bool in = lane_env < (left < kPerBlock ? (uint32_t)left : (uint32_t)kPerBlock);
+        const uint32_t sb = (uint32_t)base * 4u;
         CartPoleLane s[4];
         bool valid[4] = {in, in, in, in};
-        if (in) {
-            float4 vx = *reinterpret_cast<const float4*>(d.x() + i0), vxd = *reinterpret_cast<const float4*>(d.xd() + i0);
-            float4 vth = *reinterpret_cast<const float4*>(d.th() + i0), vthd = *reinterpret_cast<const float4*>(d.thd() + i0);
-            uint4 vc = *reinterpret_cast<const uint4*>(d.ctr() + i0);
-            s[0] = {vx.x, vxd.x, vth.x, vthd.x, vc.x}; s[1] = {vx.y, vxd.y, vth.y, vthd.y, vc.y};
-            s[2] = {vx.z, vxd.z, vth.z, vthd.z, vc.z}; s[3] = {vx.w, vxd.w, vth.w, vthd.w, vc.w};
-        } else {
-            for (int k = 0; k < 4; ++k) s[k] = {0.f, 0.f, 0.f, 0.f, 0u};
+        {   // engine columns are padded to the block's span: every lane may load; only in-range lanes store
+            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb, 0), vxd = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + colb, 0);
+            const u32x4 vth = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 2u * colb, 0), vthd = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 3u * colb, 0);
+            const u32x4 vc = __builtin_amdgcn_raw_buffer_load_b128(rs, off4, sb + 4u * colb, 0);
+            s[0] = {as_f32(vx.x), as_f32(vxd.x), as_f32(vth.x), as_f32(vthd.x), vc.x}; s[1] = {as_f32(vx.y), as_f32(vxd.y), as_f32(vth.y), as_f32(vthd.y), vc.y};
+            s[2] = {as_f32(vx.z), as_f32(vxd.z), as_f32(vth.z), as_f32(vthd.z), vc.z}; s[3] = {as_f32(vx.w), as_f32(vxd.w), as_f32(vth.w), as_f32(vthd.w), vc.w};
         }
         const uint64_t wave_first = base + (uint64_t)(threadIdx.x & ~63) * 4;
         Philox4 bits{};  // POLICY == ROLL_UNIFORM: 128 policy bits = 32 steps of this lane's 4 envs
-        for (int t = 0; t < K; ++t) {
-            const uint64_t off = (uint64_t)t * d.n + i0;
+        uint32_t so = sb;  // byte offset of (step t, this pass) in a [K][n] word buffer; byte buffers use so / 4
+        for (int t = 0; t < K; ++t, so += nb4) {
             uint32_t a[4] = {0u, 0u, 0u, 0u}, dn[4], tr[4];
             float r[4];
             if (POLICY == ROLL_TABLE) {
-                if (in) { u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(act + off)); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
+                if (in) { const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ra, off4, so, 2); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
             } else {
                 // uniform random policy: env i takes bit (t % 32) of word (i % 4) of Philox(policy_seed; lane's first
                 // global env id, policy_call, SLOT_POLICY + t / 32) — one Philox evaluation per lane per 32 steps
                 if ((t & 31) == 0) bits = env_draw(policy_seed, d.env_id_base + i0, policy_call, SLOT_POLICY + (uint32_t)(t >> 5));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[k] = (bits.w[k] >> (t & 31)) & 1u;
-                if (in && act_out) st4u<true>(act_out + off, a[0], a[1], a[2], a[3]);
+                if (in && act_out) __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], a[2], a[3]}, ra, off4, so, 2);
             }
             finished += cartpole_wave_step<4, EULER, SB, RESET>(d, s, a, valid, r, dn, tr, wave_first, lds, bad);
             if (in) {
-                if (rew) st4<true>(rew + off, r[0], r[1], r[2], r[3]);
-                if (done_out) st1u<true>(reinterpret_cast<uint32_t*>(done_out + off), dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24));
-                if (trunc_out) st1u<true>(reinterpret_cast<uint32_t*>(trunc_out + off), tr[0] | (tr[1] << 8) | (tr[2] << 16) | (tr[3] << 24));
+                if (rew) __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(r[0]), as_u32(r[1]), as_u32(r[2]), as_u32(r[3])}, rr, off4, so, 2);
+                if (done_out) __builtin_amdgcn_raw_buffer_store_b32(dn[0] | (dn[1] << 8) | (dn[2] << 16) | (dn[3] << 24), rd, lane_env, so >> 2, 2);
+                if (trunc_out) __builtin_amdgcn_raw_buffer_store_b32(tr[0] | (tr[1] << 8) | (tr[2] << 16) | (tr[3] << 24), rt, lane_env, so >> 2, 2);
                 if (obs_out) {
                     float* o = obs_out + (uint64_t)t * 4 * d.n + i0;
                     st4<true>(o, s[0].x, s[1].x, s[2].x, s[3].x); st4<true>(o + d.n, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
@@ -327,9 +336,12 @@ cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_
             }
         }
         if (in) {
-            st4<kNtStores>(d.x() + i0, s[0].x, s[1].x, s[2].x, s[3].x); st4<kNtStores>(d.xd() + i0, s[0].xd, s[1].xd, s[2].xd, s[3].xd);
-            st4<kNtStores>(d.th() + i0, s[0].th, s[1].th, s[2].th, s[3].th); st4<kNtStores>(d.thd() + i0, s[0].thd, s[1].thd, s[2].thd, s[3].thd);
-            st4u<kNtStores>(d.ctr() + i0, s[0].ctr, s[1].ctr, s[2].ctr, s[3].ctr);
+            constexpr int kAux = kNtStores ? 2 : 0;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].x), as_u32(s[1].x), as_u32(s[2].x), as_u32(s[3].x)}, rs, off4, sb, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].xd), as_u32(s[1].xd), as_u32(s[2].xd), as_u32(s[3].xd)}, rs, off4, sb + colb, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].th), as_u32(s[1].th), as_u32(s[2].th), as_u32(s[3].th)}, rs, off4, sb + 2u * colb, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{as_u32(s[0].thd), as_u32(s[1].thd), as_u32(s[2].thd), as_u32(s[3].thd)}, rs, off4, sb + 3u * colb, kAux);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{s[0].ctr, s[1].ctr, s[2].ctr, s[3].ctr}, rs, off4, sb + 4u * colb, kAux);
         }
     }
     cartpole_flush_counts(d, finished, bad);
@@ -516,7 +528,8 @@ struct CartPoleEnv final : Env {
     int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0 || K == 0) return MGYM_OK;
         const uint32_t* act = static_cast<const uint32_t*>(actions);
-        bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
+        bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16) &&
+                      (uint64_t)K * n * 4 < (1ull << 32);  // the fused kernel addresses [K][n] word buffers with 32-bit byte offsets
         if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
         launch_rollout<ROLL_TABLE>(dim3(grid_for(n / 4)), act, nullptr, 0, 0, K, obs_out, reward, done, trunc);
         MGYM_HIP(hipGetLastError());
@@ -526,8 +539,9 @@ struct CartPoleEnv final : Env {
     int rollout_uniform(uint64_t policy_seed, int K, void* actions_out, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0 || K == 0) return MGYM_OK;
         uint32_t* ao = static_cast<uint32_t*>(actions_out);
-        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16)) {
-            set_last_error("mgym_rollout_uniform: n_envs must be a multiple of 4 and the buffers 16-byte aligned");
+        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16) ||
+            (uint64_t)K * n * 4 >= (1ull << 32)) {
+            set_last_error("mgym_rollout_uniform: n_envs must be a multiple of 4, the buffers 16-byte aligned, and K * n_envs below 2^30");
             return MGYM_ERR_BAD_ARG;
         }
         launch_rollout<ROLL_UNIFORM>(dim3(grid_for(n / 4)), nullptr, ao, policy_seed, policy_calls++, K, obs_out, reward, done, trunc);
