@@ -8,8 +8,10 @@
 //   ctr[n]                                u32   — steps_since_reset | steps_beyond_terminated | episode
 //                                                 (bit layout in cartpole_step.h)
 // One lane owns 4 consecutive environments: every column is read and written with one
-// 16-byte access per lane (1 KiB per wave instruction, fully coalesced); uniform constants
-// travel in SGPRs via the kernel argument block; outputs leave with non-temporal stores.
+// 16-byte access per lane (1 KiB per wave instruction, fully coalesced).  The engine's columns are
+// addressed through ONE buffer resource — descriptor and column / pass offsets in SGPRs, one constant
+// VGPR lane offset, no per-lane address arithmetic; the physics constants (cartpole.rs:45-56: none is a
+// builder argument) are compile-time constants; outputs leave with non-temporal stores.
 // No MFMA: the path is element-wise.
 //
 // Algorithmic HBM bytes per env-step (obs_out == NULL, zero-copy observation): 50
