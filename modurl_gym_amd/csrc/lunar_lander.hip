@@ -539,10 +539,12 @@ struct LunarLanderEnv final : Env {
         }
         // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
         // grid-stride inside: the list lengths only exist on the device)
-        const unsigned gb = work_grid().x * (64 / gen_block);
+        const unsigned gb = (unsigned)(((uint64_t)work_grid().x * 64 + gen_block - 1) / gen_block);
         switch (gen_block) {
         case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
         case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(40), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(48), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
         case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
         default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
         }
