@@ -59,6 +59,12 @@ struct Xf { V2 p; Rot q; };
 struct AABB { V2 lo, hi; };
 
 #define LLD __device__ __forceinline__
+// out-of-line device functions (own register allocation; ONE copy of their local arrays in the caller's scratch frame)
+#if defined(__HIPCC__)
+#define LL_NOINLINE __device__ __noinline__
+#else
+#define LL_NOINLINE static
+#endif
 LLD V2 mk(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
 LLD V2 operator+(V2 a, V2 b) { return mk(a.x + b.x, a.y + b.y); }
 LLD V2 operator-(V2 a, V2 b) { return mk(a.x - b.x, a.y - b.y); }
@@ -187,6 +193,80 @@ struct Contact {
     int toiCount; float toi;
 };
 
+// Contact cache STORAGE.  The 12 slots x 16 words of an environment live in the engine's HBM columns ([word][n_pad],
+// lane = env index).  The manifold words (2..14) are worked on IN PLACE — they are only touched when a contact is
+// updated or enters a solver, and a local Contact[12] would take 1.1 KB of scratch per lane (the runtime caps the
+// concurrent waves of a kernel by its scratch size: profiles/r02_lunarlander/scratch_vs_concurrent_waves.txt).  The
+// three words every list walk reads — KEY, SEQ, TOI — are staged in LDS for the duration of a step (CtStore::k, one
+// column per lane): SolveTOI scans them again after every sub-step, and a chain of dependent loads costs ~100 cycles
+// each from LDS against >= 500 from L2.  Only the contact being worked on is held in registers (struct Contact).
+// Slot words: KEY SEQ LNX LNY LPX LPY P0X P0Y P0N P0T P1X P1Y P1N P1T IDS TOI.
+// KEY bits: 0 exists, 1 touching, 2 enabled, 3-4 body, 5-8 edge, 9-10 manifold type, 11-12 pointCount, 13 toiFlag,
+// 14-17 toiCount, 18 islandFlag (the last three and TOI only matter inside a step).  IDS = both contact-feature ids, 16 bits each.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LL_LDS __attribute__((address_space(3)))
+#else
+#define LL_LDS
+#endif
+struct CtHot { LL_LDS uint32_t* k; uint32_t ks; };  // staged KEY / SEQ / TOI words: word j of slot s at k[(j * kSlots + s) * ks]
+struct CtStore { uint32_t* p; uint64_t stride; CtHot hot; };
+enum : uint32_t { CK_EXISTS = 1u, CK_TOUCHING = 2u, CK_ENABLED = 4u, CK_TOIFLAG = 1u << 13, CK_ISLAND = 1u << 18 };
+constexpr uint32_t kCkRestMask = 0x1fffu;  // the key bits that persist between steps
+LLD uint32_t& ct_word(const CtStore& c, int s, int k) { return c.p[(uint64_t)(16 * s + k) * c.stride]; }  // k in 2..14
+LLD uint32_t ct_key(const CtStore& c, int s) { return c.hot.k[(uint32_t)s * c.hot.ks]; }
+LLD void ct_set_key(const CtStore& c, int s, uint32_t v) { c.hot.k[(uint32_t)s * c.hot.ks] = v; }
+LLD uint32_t ct_seq(const CtStore& c, int s) { return c.hot.k[(uint32_t)(kSlots + s) * c.hot.ks]; }
+LLD void ct_set_seq(const CtStore& c, int s, uint32_t v) { c.hot.k[(uint32_t)(kSlots + s) * c.hot.ks] = v; }
+LLD float ct_toi(const CtStore& c, int s) { return as_f32(c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks]); }
+LLD void ct_set_toi(const CtStore& c, int s, float v) { c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks] = as_u32(v); }
+LLD int ck_body(uint32_t key) { return (int)((key >> 3) & 3u); }
+LLD int ck_edge(uint32_t key) { return (int)((key >> 5) & 15u); }
+LLD int ck_toi_count(uint32_t key) { return (int)((key >> 14) & 15u); }
+// both contact-feature ids of a manifold in one word (every field is < 16: vertex / face indices < 8, types 0 / 1)
+LLD uint32_t cf16(CF a) { return (uint32_t)a.indexA | ((uint32_t)a.indexB << 4) | ((uint32_t)a.typeA << 8) | ((uint32_t)a.typeB << 12); }
+LLD CF cf16_unpack(uint32_t u) {
+    CF a; a.indexA = (uint8_t)(u & 15u); a.indexB = (uint8_t)((u >> 4) & 15u); a.typeA = (uint8_t)((u >> 8) & 15u); a.typeB = (uint8_t)((u >> 12) & 15u);
+    return a;
+}
+LLD uint32_t ct_encode_key(const Contact& c) {
+    return (c.exists ? CK_EXISTS : 0u) | (c.touching ? CK_TOUCHING : 0u) | (c.enabled ? CK_ENABLED : 0u) | ((uint32_t)c.body << 3) |
+           ((uint32_t)c.edge << 5) | ((uint32_t)c.m.type << 9) | ((uint32_t)c.m.pointCount << 11) | (c.toiFlag ? CK_TOIFLAG : 0u) |
+           (((uint32_t)c.toiCount & 15u) << 14) | (c.islandFlag ? CK_ISLAND : 0u);
+}
+LLD Contact ct_get(const CtStore& st, int s) {
+    Contact c;
+    const uint32_t key = ct_key(st, s);
+    c.exists = key & CK_EXISTS; c.touching = key & CK_TOUCHING; c.enabled = key & CK_ENABLED;
+    c.islandFlag = key & CK_ISLAND; c.toiFlag = key & CK_TOIFLAG;
+    c.body = ck_body(key); c.edge = ck_edge(key);
+    c.m.type = (int)((key >> 9) & 3u); c.m.pointCount = (int)((key >> 11) & 3u);
+    c.toiCount = ck_toi_count(key);
+    c.seq = ct_seq(st, s);
+    c.m.localNormal = mk(as_f32(ct_word(st, s, 2)), as_f32(ct_word(st, s, 3)));
+    c.m.localPoint = mk(as_f32(ct_word(st, s, 4)), as_f32(ct_word(st, s, 5)));
+    for (int p = 0; p < 2; ++p) {
+        c.m.points[p].localPoint = mk(as_f32(ct_word(st, s, 6 + 4 * p)), as_f32(ct_word(st, s, 7 + 4 * p)));
+        c.m.points[p].normalImpulse = as_f32(ct_word(st, s, 8 + 4 * p));
+        c.m.points[p].tangentImpulse = as_f32(ct_word(st, s, 9 + 4 * p));
+    }
+    const uint32_t ids = ct_word(st, s, 14);
+    c.m.points[0].id = cf16_unpack(ids); c.m.points[1].id = cf16_unpack(ids >> 16);
+    c.toi = ct_toi(st, s);
+    return c;
+}
+LLD void ct_put(const CtStore& st, int s, const Contact& c) {
+    ct_set_key(st, s, ct_encode_key(c));
+    ct_set_seq(st, s, c.seq);
+    ct_word(st, s, 2) = as_u32(c.m.localNormal.x); ct_word(st, s, 3) = as_u32(c.m.localNormal.y);
+    ct_word(st, s, 4) = as_u32(c.m.localPoint.x); ct_word(st, s, 5) = as_u32(c.m.localPoint.y);
+    for (int p = 0; p < 2; ++p) {
+        ct_word(st, s, 6 + 4 * p) = as_u32(c.m.points[p].localPoint.x); ct_word(st, s, 7 + 4 * p) = as_u32(c.m.points[p].localPoint.y);
+        ct_word(st, s, 8 + 4 * p) = as_u32(c.m.points[p].normalImpulse); ct_word(st, s, 9 + 4 * p) = as_u32(c.m.points[p].tangentImpulse);
+    }
+    ct_word(st, s, 14) = cf16(c.m.points[0].id) | (cf16(c.m.points[1].id) << 16);
+    ct_set_toi(st, s, c.toi);
+}
+
 struct ClipV { V2 v; CF id; };
 
 LLD int clip_segment(ClipV vOut[2], const ClipV vIn[2], V2 normal, float offset, int vertexIndexA) {  // b2ClipSegmentToLine
@@ -208,7 +288,7 @@ LLD int clip_segment(ClipV vOut[2], const ClipV vIn[2], V2 normal, float offset,
 }
 
 // b2CollideEdgeAndPolygon (v2.4.1 form), two-sided edge in the ground frame (xfA = identity => xf = xfB)
-LLD void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab, int pi, Xf xfB) {
+LL_NOINLINE void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab, int pi, Xf xfB) {
     manifold.pointCount = 0;
     const Xf xf = xfB;
     V2 edge1 = v2 - v1;

@@ -51,7 +51,10 @@ struct LLDev {
     //   0 = general steps, 1 = resets (fast path), 2 = resets the fast path declined (general path)
     uint32_t* work_list;
     uint32_t* work_count;
-    LLConst k;
+    LLConst k;          // host copy (builder arguments folded into constants)
+    const LLConst* kd;  // the same in device memory: kernels read the constants through this pointer (scalar loads), so the
+                        // by-value kernel argument never has its address taken — otherwise every lane keeps a private copy
+                        // of it in scratch (~400 B/lane), and scratch size caps the number of concurrent waves
     int auto_reset;
     int bucket;  // worklist bucketing by F_TOUCHING
 };
@@ -70,16 +73,10 @@ struct EnvRegs {  // LunarLanderV3 fields beside the world (lunar_lander.rs:232-
 };
 
 #define ST(col) d.st[(uint64_t)(col) * d.n_pad + i]
-
-// both contact-feature ids of a manifold in one word (every field is < 16: vertex / face indices < 8, types 0 / 1)
-__device__ __forceinline__ uint32_t cf16(CF a) { return (uint32_t)a.indexA | ((uint32_t)a.indexB << 4) | ((uint32_t)a.typeA << 8) | ((uint32_t)a.typeB << 12); }
-__device__ __forceinline__ CF cf16_unpack(uint32_t u) {
-    CF a; a.indexA = (uint8_t)(u & 15u); a.indexB = (uint8_t)((u >> 4) & 15u); a.typeA = (uint8_t)((u >> 8) & 15u); a.typeB = (uint8_t)((u >> 12) & 15u);
-    return a;
-}
+#define LLK(d) (*(d).kd)
 
 // mid = true: continue an unfinished SolveTOI (the env was stored by ll_store(..., mid = true) earlier in this step)
-__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e, bool mid = false) {
+__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e, CtHot hot, bool mid = false) {
     const uint32_t flags = ST(C_FLAGS);
     for (int b = 0; b < 3; ++b) {
         Body& bd = w.b[b];
@@ -91,7 +88,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
         bd.w = as_f32(ST(c + 7));
         bd.sleepTime = as_f32(ST(c + 8));
         bd.xf.q = rot_set(bd.sw.a);
-        bd.sw.localCenter = d.k.localCenter[b == 0 ? 0 : 1];
+        bd.sw.localCenter = LLK(d).localCenter[b == 0 ? 0 : 1];
         bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a; bd.sw.alpha0 = 0.0f;
         if (mid) {
             bd.sw.c0 = mk(as_f32(ST(C_MID + 4 * b + 0)), as_f32(ST(C_MID + 4 * b + 1)));
@@ -119,29 +116,12 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     w.game_over = flags & F_GAME_OVER;
     w.legs[0] = flags & F_LEG0; w.legs[1] = flags & F_LEG1;
     w.overflow = 0u; w.terrain_dirty = false;
-    const uint32_t ncont = (flags >> F_NCONTACT_SHIFT) & 15u;
+    // the contact cache: manifold words in place, KEY / SEQ / TOI staged in `hot` for the step (ll_b2.h)
+    w.cs.p = &ST(C_CONTACT); w.cs.stride = d.n_pad; w.cs.hot = hot;
     for (int s = 0; s < kSlots; ++s) {
-        Contact& ct = w.ct[s];
-        ct.exists = false;
-        if (ncont == 0) continue;
-        const int c = C_CONTACT + 16 * s;
-        const uint32_t key = ST(c + 0);
-        if (!(key & 1u)) continue;
-        ct.exists = true; ct.touching = key & 2u; ct.enabled = key & 4u; ct.islandFlag = false; ct.toiFlag = false;
-        ct.body = (key >> 3) & 3u; ct.edge = (key >> 5) & 15u;
-        ct.m.type = (key >> 9) & 3u; ct.m.pointCount = (key >> 11) & 3u;
-        ct.seq = ST(c + 1);
-        ct.m.localNormal = mk(as_f32(ST(c + 2)), as_f32(ST(c + 3)));
-        ct.m.localPoint = mk(as_f32(ST(c + 4)), as_f32(ST(c + 5)));
-        for (int p = 0; p < 2; ++p) {
-            ct.m.points[p].localPoint = mk(as_f32(ST(c + 6 + 4 * p)), as_f32(ST(c + 7 + 4 * p)));
-            ct.m.points[p].normalImpulse = as_f32(ST(c + 8 + 4 * p));
-            ct.m.points[p].tangentImpulse = as_f32(ST(c + 9 + 4 * p));
-        }
-        const uint32_t ids = ST(c + 14);
-        ct.m.points[0].id = cf16_unpack(ids); ct.m.points[1].id = cf16_unpack(ids >> 16);
-        ct.toiCount = 0; ct.toi = 1.0f;
-        if (mid) { ct.toiFlag = (key >> 13) & 1u; ct.toiCount = (int)((key >> 14) & 15u); ct.toi = as_f32(ST(c + 15)); }
+        ct_set_key(w.cs, s, ST(C_CONTACT + 16 * s + 0));
+        ct_set_seq(w.cs, s, ST(C_CONTACT + 16 * s + 1));
+        if (mid) ct_set_toi(w.cs, s, as_f32(ST(C_CONTACT + 16 * s + 15)));
     }
     e.prev_shaping = as_f32(ST(C_PREV));
     e.prev_some = flags & F_PREV_SOME;
@@ -179,27 +159,15 @@ __device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World
     if (w.terrain_dirty)
         for (int q = 0; q < kEdges; ++q) ST(C_SMOOTH + q) = as_u32(w.smooth[q]);
     ST(C_SEQ) = w.next_seq;
-    const uint32_t old_ncont = (ST(C_FLAGS) >> F_NCONTACT_SHIFT) & 15u;
-    for (int s = 0; s < kSlots; ++s) ncont += w.ct[s].exists ? 1u : 0u;
-    if (ncont || old_ncont) {
-        for (int s = 0; s < kSlots; ++s) {
-            const Contact& ct = w.ct[s];
-            const int c = C_CONTACT + 16 * s;
-            if (!ct.exists) { ST(c + 0) = 0u; continue; }
-            touching |= ct.touching ? 1u : 0u;
-            ST(c + 0) = 1u | (ct.touching ? 2u : 0u) | (ct.enabled ? 4u : 0u) | ((uint32_t)ct.body << 3) | ((uint32_t)ct.edge << 5) |
-                        ((uint32_t)ct.m.type << 9) | ((uint32_t)ct.m.pointCount << 11) |
-                        (mid ? ((ct.toiFlag ? 1u : 0u) << 13) | (((uint32_t)ct.toiCount & 15u) << 14) : 0u);
-            ST(c + 1) = ct.seq;
-            ST(c + 2) = as_u32(ct.m.localNormal.x); ST(c + 3) = as_u32(ct.m.localNormal.y);
-            ST(c + 4) = as_u32(ct.m.localPoint.x); ST(c + 5) = as_u32(ct.m.localPoint.y);
-            for (int p = 0; p < 2; ++p) {
-                ST(c + 6 + 4 * p) = as_u32(ct.m.points[p].localPoint.x); ST(c + 7 + 4 * p) = as_u32(ct.m.points[p].localPoint.y);
-                ST(c + 8 + 4 * p) = as_u32(ct.m.points[p].normalImpulse); ST(c + 9 + 4 * p) = as_u32(ct.m.points[p].tangentImpulse);
-            }
-            ST(c + 14) = cf16(ct.m.points[0].id) | (cf16(ct.m.points[1].id) << 16);
-            if (mid) ST(c + 15) = as_u32(ct.toi);
-        }
+    for (int s = 0; s < kSlots; ++s) {  // the manifolds are already in their columns; the staged words go back
+        uint32_t key = ct_key(w.cs, s);
+        if (!mid) key &= kCkRestMask;  // in-step bits (toiFlag, toiCount, islandFlag) do not persist
+        ST(C_CONTACT + 16 * s + 0) = key;
+        if (!(key & CK_EXISTS)) continue;
+        ST(C_CONTACT + 16 * s + 1) = ct_seq(w.cs, s);
+        if (mid) ST(C_CONTACT + 16 * s + 15) = as_u32(ct_toi(w.cs, s));
+        ++ncont;
+        touching |= (key & CK_TOUCHING) ? 1u : 0u;
     }
     flags |= (w.game_over ? F_GAME_OVER : 0u) | (w.legs[0] ? F_LEG0 : 0u) | (w.legs[1] ? F_LEG1 : 0u) |
              (e.has_world ? F_HAS_WORLD : 0u) | (e.deterministic ? F_DETERMINISTIC : 0u) |
@@ -360,7 +328,7 @@ __device__ __forceinline__ void ll_build_scene(World& w, EnvRegs& e, const PolyT
         w.fat[b].hi = mk(a.hi.x + b2_aabbExtension, a.hi.y + b2_aabbExtension);
     }
     for (int j = 0; j < 2; ++j) { w.jt[j].impulse = mk(0.0f, 0.0f); w.jt[j].motorImpulse = 0.0f; w.jt[j].lowerImpulse = 0.0f; w.jt[j].upperImpulse = 0.0f; }
-    for (int s = 0; s < kSlots; ++s) w.ct[s].exists = false;
+    for (int s = 0; s < kSlots; ++s) ct_set_key(w.cs, s, 0u);  // (ll_load pointed w.cs at the env's contact storage)
     w.next_seq = 1u; w.pending = 7u; w.newContacts = true; w.stepped_once = false;
     w.game_over = false; w.legs[0] = w.legs[1] = false; w.overflow = 0u;
     if (random_force) {  // :845-849
@@ -395,7 +363,7 @@ __device__ __forceinline__ void ll_reset_scene(const LLDev& d, uint64_t i, World
     for (int q = 0; q < 12; ++q) height[q] = u23(r[q]) * (H / 2.0f - 0.0f) + 0.0f;  // :755
     int32_t wi = -9999 + (int32_t)(((uint64_t)r[14] * 19998u) >> 32);               // :855-856
     int32_t ti = -9999 + (int32_t)(((uint64_t)r[15] * 19998u) >> 32);
-    ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE, true, u23(r[12]), u23(r[13]), wi, ti, false);
+    ll_build_scene(w, e, tab, LLK(d), height, VIEWPORT_H / SCALE, true, u23(r[12]), u23(r[13]), wi, ti, false);
     e.step = 0u;
 }
 
@@ -404,7 +372,7 @@ __device__ inline void ll_env_reset(const LLDev& d, uint64_t i, World& w, EnvReg
     ll_reset_scene(d, i, w, e, tab);
     float d0, d1, reward; uint32_t done;
     ll_dispersion(d, i, e, d0, d1);
-    ll_env_step(w, e, tab, d.k, mem, 0u, d0, d1, state, reward, done);  // :911-916
+    ll_env_step(w, e, tab, LLK(d), mem, 0u, d0, d1, state, reward, done);  // :911-916
     e.episode += 1u;
 }
 

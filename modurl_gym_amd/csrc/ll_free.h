@@ -33,7 +33,7 @@ __device__ __forceinline__ void ll_free_load(const LLDev& d, uint64_t i, FreeReg
         bd.v = mk(as_f32(ST(c + 5)), as_f32(ST(c + 6)));
         bd.w = as_f32(ST(c + 7));
         bd.sleepTime = as_f32(ST(c + 8));
-        bd.sw.localCenter = d.k.localCenter[b == 0 ? 0 : 1];
+        bd.sw.localCenter = LLK(d).localCenter[b == 0 ? 0 : 1];
         bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a; bd.sw.alpha0 = 0.0f;
         bd.force = mk(0.0f, 0.0f); bd.torque = 0.0f;
         bd.awake = true; bd.islandFlag = false;
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool ll_free_move_proxy(AABB& tree, AABB aabb, V2 dis
 // must go through the general path instead.
 __device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
                                                  float disp0, float disp1, float state[8], float& reward, uint32_t& done) {
-    const LLConst& k = d.k;
+    const LLConst& k = LLK(d);
     if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
         for (int b = 0; b < 3; ++b)
             if ((f.flags >> 9) & (1u << b))

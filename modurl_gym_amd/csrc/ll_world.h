@@ -14,6 +14,9 @@
 #define LL_DIAG_SWEEP(kind, it, ...)   // diagnostic builds hash the sweep state to look for short cycles
 #define LL_DIAG_SWEEP_END(kind)
 #endif
+#ifndef LL_TOI_SWEEP_STAT
+#define LL_TOI_SWEEP_STAT(count, done)  // host statistics builds count the sweeps a sub-step really ran
+#endif
 
 namespace mgym {
 namespace ll {
@@ -28,7 +31,7 @@ struct Joint {  // b2RevoluteJoint, bodyA = lander (0), bodyB = leg (1 + j)
 
 struct World {
     Body b[3];
-    Contact ct[kSlots];
+    CtStore cs;             // the env's contact-cache slots, in place in the engine's columns (ll_b2.h)
     Joint jt[2];
     float smooth[kEdges];   // terrain heights smooth_y[0..10] (lunar_lander.rs:772-774)
     AABB fat[3];            // broad-phase AABBs of the three polygon proxies
@@ -117,8 +120,9 @@ LLD bool body_sync_fixtures(World& w, const PolyTab& tab, int body) {  // b2Body
 }
 
 LLD int find_slot(const World& w, int body, int edge) {
+    const uint32_t want = CK_EXISTS | ((uint32_t)body << 3) | ((uint32_t)edge << 5), mask = CK_EXISTS | (3u << 3) | (15u << 5);
     for (int s = 0; s < kSlots; ++s)
-        if (w.ct[s].exists && w.ct[s].body == body && w.ct[s].edge == edge) return s;
+        if ((ct_key(w.cs, s) & mask) == want) return s;
     return -1;
 }
 // b2ContactManager::AddPair (ground edge, dynamic polygon)
@@ -126,14 +130,12 @@ LLD void add_pair(World& w, int edge, int body) {
     if (find_slot(w, body, edge) >= 0) return;
     int s = -1;
     for (int k = 0; k < kSlots; ++k)
-        if (!w.ct[k].exists) { s = k; break; }
+        if (!(ct_key(w.cs, k) & CK_EXISTS)) { s = k; break; }
     if (s < 0) { w.overflow |= 1u; return; }
-    Contact& c = w.ct[s];
-    c.exists = true; c.touching = false; c.enabled = true; c.islandFlag = false; c.toiFlag = false;
-    c.seq = w.next_seq++;
-    c.body = body; c.edge = edge;
-    c.m.pointCount = 0; c.m.type = 0;
-    c.toiCount = 0; c.toi = 1.0f;
+    // a fresh contact: only the key, the sequence number and the cached time of impact are meaningful (pointCount = 0)
+    ct_set_key(w.cs, s, CK_EXISTS | CK_ENABLED | ((uint32_t)body << 3) | ((uint32_t)edge << 5));
+    ct_set_seq(w.cs, s, w.next_seq++);
+    ct_set_toi(w.cs, s, 1.0f);
 }
 // b2BroadPhase::UpdatePairs for the buffered moves `order[0..n)` (dynamic proxies; partners = ground edges
 // by ascending proxy id — the brute-force stand-in for the dynamic-tree query, as in the CPU oracle)
@@ -184,13 +186,20 @@ LLD void contact_update(World& w, const PolyTab& tab, Contact& c) {  // b2Contac
 
 // contact list order: newest first
 LLD int contact_order(const World& w, int* order) {
+    // rank of a contact = the number of contacts created after it; keys and sequence numbers are read once with
+    // static indices (registers), so nothing here waits on a chain of dependent loads
+    uint32_t key[kSlots], seq[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) { key[s] = ct_key(w.cs, s); seq[s] = ct_seq(w.cs, s); }
     int n = 0;
-    for (int s = 0; s < kSlots; ++s)
-        if (w.ct[s].exists) order[n++] = s;
-    for (int i = 1; i < n; ++i) {
-        int k = order[i], j = i - 1;
-        while (j >= 0 && w.ct[order[j]].seq < w.ct[k].seq) { order[j + 1] = order[j]; --j; }
-        order[j + 1] = k;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        if (!(key[s] & CK_EXISTS)) continue;
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) rank += ((key[t] & CK_EXISTS) && seq[t] > seq[s]) ? 1 : 0;
+        order[rank] = s;
+        ++n;
     }
     return n;
 }
@@ -199,15 +208,18 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
     int order[kSlots];
     int n = contact_order(w, order);
     for (int k = 0; k < n; ++k) {
-        Contact& c = w.ct[order[k]];
-        if (!w.b[c.body].awake) continue;
-        if (!aabb_overlap(edge_fat(w, c.edge), w.fat[c.body])) {  // b2ContactManager::Destroy
-            if (c.touching) on_end(w, c.body);
-            if (c.m.pointCount > 0) body_set_awake(w.b[c.body], true);
-            c.exists = false;
+        const uint32_t key = ct_key(w.cs, order[k]);
+        const int body = ck_body(key), edge = ck_edge(key);
+        if (!w.b[body].awake) continue;
+        if (!aabb_overlap(edge_fat(w, edge), w.fat[body])) {  // b2ContactManager::Destroy
+            if (key & CK_TOUCHING) on_end(w, body);
+            if (((key >> 11) & 3u) > 0u) body_set_awake(w.b[body], true);
+            ct_set_key(w.cs, order[k], 0u);
             continue;
         }
+        Contact c = ct_get(w.cs, order[k]);
         contact_update(w, tab, c);
+        ct_put(w.cs, order[k], c);
     }
 }
 
@@ -284,7 +296,7 @@ LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, 
     if (count > mem.cap) { w.overflow |= 2u; count = mem.cap; }
     s.count = count;
     for (int i = 0; i < count; ++i) {
-        Contact& contact = w.ct[slots[i]];
+        const Contact contact = ct_get(w.cs, slots[i]);
         const Manifold& manifold = contact.m;
         const int t = poly_of(contact.body);
         VConstraint& vc = s.vc[i * s.vs];
@@ -320,7 +332,7 @@ LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel3
     for (int i = 0; i < s.count; ++i) {
         VConstraint& vc = s.vc[i * s.vs];
         const PConstraint& pc = s.pc[i * s.ps];
-        const Manifold& manifold = w.ct[vc.slot].m;
+        const Manifold manifold = ct_get(w.cs, vc.slot).m;
         const float mB = vc.invMassB, iB = vc.invIB;
         V2 cB = pos[vc.indexB].c; float aB = pos[vc.indexB].a;
         const Vel velB = vel_get(vel, vc.indexB);
@@ -468,10 +480,9 @@ LLD void cs_solve_one_on(VConstraint& vc, int body, Vel3& vel) {
 LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::StoreImpulses
     for (int i = 0; i < s.count; ++i) {
         const VConstraint& vc = s.vc[i * s.vs];
-        Manifold& manifold = w.ct[vc.slot].m;
         for (int j = 0; j < vc.pointCount; ++j) {
-            manifold.points[j].normalImpulse = vc.points[j].normalImpulse;
-            manifold.points[j].tangentImpulse = vc.points[j].tangentImpulse;
+            ct_word(w.cs, vc.slot, 8 + 4 * j) = as_u32(vc.points[j].normalImpulse);
+            ct_word(w.cs, vc.slot, 9 + 4 * j) = as_u32(vc.points[j].tangentImpulse);
         }
     }
 }
@@ -679,11 +690,6 @@ LLD float sleep_update(Body& b, float h, float minSleepTime) {
 // register-starved, so the hot loop gets its own register allocation (state is copied in, iterated in VGPRs,
 // copied out).  The first two contact constraints ride in registers (their LDS copies could not be kept in
 // registers by the compiler: every impulse store may alias them); the rest stay in LDS.
-#if defined(__HIPCC__)
-#define LL_NOINLINE __device__ __noinline__
-#else
-#define LL_NOINLINE static
-#endif
 LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver& cs, const int* cstart, const int* ibody, int nb,
                                bool leg1_first, const LLConst& k_in, float dt, float inv_dt) {
     Joint J0 = J0_io, J1 = J1_io;
@@ -745,40 +751,59 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
 }
 
 // the 180 contact-only sweeps of b2Island::SolveTOI on the one dynamic body (impulses are not stored back).
-// A sweep is a pure function of (body velocity, accumulated impulses); when one sweep leaves every word of that
-// state bit-for-bit unchanged, all later sweeps would too, so the loop stops there with the identical result.
-// One body against static ground usually reaches such a fixed point within a few dozen sweeps (the joints of
-// the full island never do, which is why island_sweeps has no such exit).
+// A sweep is a pure function F of the state S = (body velocity, accumulated impulses) — everything else in the
+// constraints is constant — so the sequence S_0, S_1 = F(S_0), ... is eventually periodic, and in f32 it usually
+// becomes so within a few dozen sweeps: one body against static ground settles on a fixed point (period 1) or on a
+// short cycle of last-bit flips.  Once S_j == S_i bit for bit (i < j, p = j - i), S_180 = S_{j + (180 - j) mod p}:
+// only (180 - j) mod p more sweeps are run, with the identical result.  S_j is compared with the previous state
+// (fixed point, found at once) and with a snapshot renewed at j = 1, 2, 4, 8, ... (Brent's cycle search: any period
+// is found once the snapshot lies on the cycle and the window exceeds the period).  The joints of the full island
+// never settle this way, which is why island_sweeps has no such exit.
+struct ToiSweepState { uint32_t w[11]; };
+LLD bool toi_state_same(const ToiSweepState& a, const ToiSweepState& b) {
+    bool same = true;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) same = same && a.w[q] == b.w[q];
+    return same;
+}
 LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
     Vel vd = vd_io;
     VConstraint r0, r1;
     const bool h0 = cs.count > 0, h1 = cs.count > 1;
     if (h0) r0 = cs.vc[0];
     if (h1) r1 = cs.vc[cs.vs];
-    const bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
+    bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
+    auto state_now = [&]() {
+        ToiSweepState st;
+        st.w[0] = as_u32(vd.v.x); st.w[1] = as_u32(vd.v.y); st.w[2] = as_u32(vd.w);
+        st.w[3] = h0 ? as_u32(r0.points[0].normalImpulse) : 0u; st.w[4] = h0 ? as_u32(r0.points[0].tangentImpulse) : 0u;
+        st.w[5] = h0 ? as_u32(r0.points[1].normalImpulse) : 0u; st.w[6] = h0 ? as_u32(r0.points[1].tangentImpulse) : 0u;
+        st.w[7] = h1 ? as_u32(r1.points[0].normalImpulse) : 0u; st.w[8] = h1 ? as_u32(r1.points[0].tangentImpulse) : 0u;
+        st.w[9] = h1 ? as_u32(r1.points[1].normalImpulse) : 0u; st.w[10] = h1 ? as_u32(r1.points[1].tangentImpulse) : 0u;
+        return st;
+    };
+    ToiSweepState prev = state_now(), snap = prev;
+    int done = 0, left = 180, snap_at = 0, next_snap = 1;
     LL_DIAG_SWEEP_BEGIN(1);
-    for (int i = 0; i < 180; ++i) {
-        const Vel v_before = vd;
-        float n00 = 0.0f, t00 = 0.0f, n01 = 0.0f, t01 = 0.0f, n10 = 0.0f, t10 = 0.0f, n11 = 0.0f, t11 = 0.0f;
-        if (h0) { n00 = r0.points[0].normalImpulse; t00 = r0.points[0].tangentImpulse; n01 = r0.points[1].normalImpulse; t01 = r0.points[1].tangentImpulse; }
-        if (h1) { n10 = r1.points[0].normalImpulse; t10 = r1.points[0].tangentImpulse; n11 = r1.points[1].normalImpulse; t11 = r1.points[1].tangentImpulse; }
+    while (left > 0) {
         if (h0) cs_solve_one(r0, vd);
         if (h1) cs_solve_one(r1, vd);
         if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
+        ++done; --left;
         if (can_stop) {
-            bool same = as_u32(vd.v.x) == as_u32(v_before.v.x) && as_u32(vd.v.y) == as_u32(v_before.v.y) && as_u32(vd.w) == as_u32(v_before.w);
-            if (h0) same = same && as_u32(n00) == as_u32(r0.points[0].normalImpulse) && as_u32(t00) == as_u32(r0.points[0].tangentImpulse) &&
-                           as_u32(n01) == as_u32(r0.points[1].normalImpulse) && as_u32(t01) == as_u32(r0.points[1].tangentImpulse);
-            if (h1) same = same && as_u32(n10) == as_u32(r1.points[0].normalImpulse) && as_u32(t10) == as_u32(r1.points[0].tangentImpulse) &&
-                           as_u32(n11) == as_u32(r1.points[1].normalImpulse) && as_u32(t11) == as_u32(r1.points[1].tangentImpulse);
-            LL_DIAG_SWEEP(1, i, true, vd.v.x, vd.v.y, vd.w, h0 ? r0.points[0].normalImpulse : 0.0f, h0 ? r0.points[0].tangentImpulse : 0.0f,
+            const ToiSweepState cur = state_now();
+            LL_DIAG_SWEEP(1, done - 1, true, vd.v.x, vd.v.y, vd.w, h0 ? r0.points[0].normalImpulse : 0.0f, h0 ? r0.points[0].tangentImpulse : 0.0f,
                           h0 && r0.pointCount > 1 ? r0.points[1].normalImpulse : 0.0f, h0 && r0.pointCount > 1 ? r0.points[1].tangentImpulse : 0.0f,
                           h1 ? r1.points[0].normalImpulse : 0.0f, h1 ? r1.points[0].tangentImpulse : 0.0f,
                           h1 && r1.pointCount > 1 ? r1.points[1].normalImpulse : 0.0f, h1 && r1.pointCount > 1 ? r1.points[1].tangentImpulse : 0.0f);
-            if (same) break;
+            if (toi_state_same(cur, prev)) break;                                                // fixed point
+            if (toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
+            else if (done == next_snap) { snap = cur; snap_at = done; next_snap *= 2; }
+            prev = cur;
         }
     }
     LL_DIAG_SWEEP_END(1);
+    LL_TOI_SWEEP_STAT(cs.count, done);
     vd_io = vd;
 }
 
@@ -850,7 +875,7 @@ LL_NOINLINE void toi_position(const CSolver& cs, Pos& p_io) {
 // ---- b2World::Solve + b2Island::Solve --------------------------------------------------------------------
 LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, float inv_dt, float dtRatio) {
     for (int i = 0; i < 3; ++i) w.b[i].islandFlag = false;
-    for (int s = 0; s < kSlots; ++s) w.ct[s].islandFlag = false;
+    for (int s = 0; s < kSlots; ++s) ct_set_key(w.cs, s, ct_key(w.cs, s) & ~CK_ISLAND);
     int seed = -1;
     for (int i = 2; i >= 0; --i)
         if (w.b[i].awake) { seed = i; break; }
@@ -871,11 +896,11 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         ibody[nb++] = bi;
         w.b[bi].awake = true;
         for (int q = 0; q < n_order; ++q) {
-            Contact& c = w.ct[order[q]];
-            if (c.body != bi || c.islandFlag) continue;
-            if (!c.enabled || !c.touching) continue;
+            const uint32_t key = ct_key(w.cs, order[q]);
+            if (ck_body(key) != bi || (key & CK_ISLAND)) continue;
+            if (!(key & CK_ENABLED) || !(key & CK_TOUCHING)) continue;
             icontact[nc++] = order[q];
-            c.islandFlag = true;
+            ct_set_key(w.cs, order[q], key | CK_ISLAND);
             if (groundFlag) continue;
             stack[sc++] = 3; groundFlag = true;
         }
@@ -966,20 +991,25 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
         bool any = false;
         for (int s = 0; s < kSlots; ++s) {
-            Contact& c = w.ct[s];
-            if (!c.exists) continue;
+            const uint32_t key = ct_key(w.cs, s);
+            if (!(key & CK_EXISTS)) continue;
             any = true;
-            c.toiFlag = false; c.islandFlag = false; c.toiCount = 0; c.toi = 1.0f;
+            ct_set_key(w.cs, s, key & kCkRestMask);  // toiFlag = islandFlag = false, toiCount = 0
+            ct_set_toi(w.cs, s, 1.0f);
         }
         w.gA = 0.0f;
         if (!any) return true;
     }
     float gA = w.gA;
+    // the contact list, newest first: SolveTOI only ever adds contacts (FindNewContacts after a sub-step), so the
+    // order is rebuilt when the sequence counter has moved and not on every pass
+    int order[kSlots];
+    int n_order = contact_order(w, order);
+    uint32_t order_seq = w.next_seq;
     for (;;) {
         int minSlot = -1;
         float minAlpha = 1.0f;
-        int order[kSlots];
-        const int n_order = contact_order(w, order);
+        if (w.next_seq != order_seq) { n_order = contact_order(w, order); order_seq = w.next_seq; }
         // b2World::SolveTOI walks the contact list once, computing the time of impact of every contact whose cached
         // value was invalidated and tracking the minimum.  Here the walk is split into three passes with the same
         // per-contact order and arithmetic: (1) list the contacts that need a computation, (2) compute them —
@@ -987,43 +1017,45 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         // time_of_impact max-over-lanes(own count) times instead of once per list position — (3) take the minimum.
         int need[kSlots], n_need = 0;
         for (int q = 0; q < n_order; ++q) {
-            const Contact& c = w.ct[order[q]];
-            if (!c.enabled || c.toiCount > b2_maxSubSteps || c.toiFlag) continue;
-            if (!w.b[c.body].awake) continue;
+            const uint32_t key = ct_key(w.cs, order[q]);
+            if (!(key & CK_ENABLED) || ck_toi_count(key) > b2_maxSubSteps || (key & CK_TOIFLAG)) continue;
+            if (!w.b[ck_body(key)].awake) continue;
             need[n_need++] = order[q];
         }
         for (int j = 0; j < n_need; ++j) {
-            Contact& c = w.ct[need[j]];
-            Body& bB = w.b[c.body];
+            const uint32_t key = ct_key(w.cs, need[j]);
+            const int body = ck_body(key);
+            Body& bB = w.b[body];
             // put the sweeps onto the same time interval (the shared static body carries an alpha0 too)
             float alpha0 = gA;
             if (gA < bB.sw.alpha0) { alpha0 = bB.sw.alpha0; gA = alpha0; }
             else if (bB.sw.alpha0 < gA) { alpha0 = gA; sweep_advance(bB.sw, alpha0); }
             V2 ev[2];
-            edge_verts(w, c.edge, ev[0], ev[1]);
+            edge_verts(w, ck_edge(key), ev[0], ev[1]);
             float beta;
             LL_STAMP(8);
-            int state = time_of_impact(ev, tab, poly_of(c.body), bB.sw, beta);
+            int state = time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
             LL_STAMP(9);
             float alpha;
             if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
             else alpha = 1.0f;
-            c.toi = alpha;
-            c.toiFlag = true;
+            ct_set_toi(w.cs, need[j], alpha);
+            ct_set_key(w.cs, need[j], key | CK_TOIFLAG);
         }
         for (int q = 0; q < n_order; ++q) {
-            const Contact& c = w.ct[order[q]];
-            if (!c.enabled) continue;
-            if (c.toiCount > b2_maxSubSteps) continue;
-            if (!c.toiFlag) continue;  // body asleep: skipped by the reference before any computation
-            const float alpha = c.toi;
+            const uint32_t key = ct_key(w.cs, order[q]);
+            if (!(key & CK_ENABLED)) continue;
+            if (ck_toi_count(key) > b2_maxSubSteps) continue;
+            if (!(key & CK_TOIFLAG)) continue;  // body asleep: skipped by the reference before any computation
+            const float alpha = ct_toi(w.cs, order[q]);
             if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
         }
+        LL_STAMP(16);
         if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) { w.gA = gA; return true; }
         if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
         if (budget > 0) --budget;
 
-        Contact& minContact = w.ct[minSlot];
+        Contact minContact = ct_get(w.cs, minSlot);
         const int dyn = minContact.body;
         Body& bB = w.b[dyn];
         Sweep backup = bB.sw;
@@ -1035,23 +1067,32 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         ++minContact.toiCount;
         if (!minContact.enabled || !minContact.touching) {
             minContact.enabled = false;
+            ct_put(w.cs, minSlot, minContact);
             bB.sw = backup;
             gA = gA_backup;
             body_sync_transform(bB);
             continue;
         }
         body_set_awake(bB, true);
+        LL_STAMP(17);
 
         int islandSlots[kSlots], nc = 0;
         islandSlots[nc++] = minSlot;
         minContact.islandFlag = true;
+        ct_put(w.cs, minSlot, minContact);
+        // the body's other contacts, in list order; listed first so that the lanes of a wave run contact_update once per
+        // list position of their own (an update changes no other contact's key)
+        int upd[kSlots], n_upd = 0;
         for (int q = 0; q < n_order; ++q) {
-            Contact& c = w.ct[order[q]];
-            if (!c.exists || c.body != dyn || c.islandFlag) continue;
+            const uint32_t key = ct_key(w.cs, order[q]);
+            if (!(key & CK_EXISTS) || ck_body(key) != dyn || (key & CK_ISLAND)) continue;
+            upd[n_upd++] = order[q];
+        }
+        for (int j = 0; j < n_upd; ++j) {
+            Contact c = ct_get(w.cs, upd[j]);
             contact_update(w, tab, c);
-            if (!c.enabled || !c.touching) continue;
-            c.islandFlag = true;
-            islandSlots[nc++] = order[q];
+            if (c.enabled && c.touching) { c.islandFlag = true; islandSlots[nc++] = upd[j]; }
+            ct_put(w.cs, upd[j], c);
         }
 
         // b2Island::SolveTOI: positions/velocities of the one dynamic body (slot `dyn` of a 3-entry table)
@@ -1085,9 +1126,12 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         LL_STAMP(11);
         int moved[1], nm = 0;
         if (body_sync_fixtures(w, tab, dyn)) moved[nm++] = dyn;
-        for (int s = 0; s < kSlots; ++s)
-            if (w.ct[s].exists && w.ct[s].body == dyn) { w.ct[s].toiFlag = false; w.ct[s].islandFlag = false; }
+        for (int s = 0; s < kSlots; ++s) {
+            const uint32_t key = ct_key(w.cs, s);
+            if ((key & CK_EXISTS) && ck_body(key) == dyn) ct_set_key(w.cs, s, key & ~(CK_TOIFLAG | CK_ISLAND));
+        }
         find_new_contacts(w, moved, nm);
+        LL_STAMP(18);
     }
 }
 

@@ -35,7 +35,12 @@ constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no in
 // Touching contacts one island may hold.  9 is the geometric bound of this scene: a body's polygon spans < 2 m (lander
 // 1.13 m, leg diagonal 0.55 m) while terrain edges are 2 m wide, so it can touch at most two adjacent terrain edges plus
 // the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (LDS: 9 x 32 lanes x 124 B = 35.7 KB per block.)
-constexpr int kSolverCap = 9;
+#ifndef LL_SOLVER_CAP
+#define LL_SOLVER_CAP 9
+#endif
+constexpr int kSolverCap = LL_SOLVER_CAP;
+// the staged KEY / SEQ / TOI words of the contact cache (ll_b2.h CtHot): one LDS column per lane of the block
+#define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ)}
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 // Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
 //   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
@@ -98,7 +103,7 @@ template <int OCC>
 __global__ void __launch_bounds__(kLLBlock, OCC)
 ll_free_kernel(LLDev d, LLIo io) {
     __shared__ PolyTab tab;
-    stage_tab(tab, d.k);
+    stage_tab(tab, LLK(d));
     bool not_reset = false;
     uint32_t finished = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -160,7 +165,8 @@ __global__ void __launch_bounds__(BLK)
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kSolverCap * BLK];
-    stage_tab(tab, d.k);
+    LL_HOT_DECL(BLK);
+    stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
@@ -179,7 +185,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
         if (have) {
             i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
             World w; EnvRegs e;
-            ll_load(d, i, w, e);
+            ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
                 if (io.rew) io.rew[i] = 0.0f;
@@ -189,7 +195,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
                 const uint32_t action = io.act[i];
                 float d0, d1;
                 ll_dispersion(d, i, e, d0, d1);
-                if (ll_step_begin(w, e, tab, d.k, mem, action, d0, d1, toi_budget)) {
+                if (ll_step_begin(w, e, tab, LLK(d), mem, action, d0, d1, toi_budget)) {
                     float state[8], reward; uint32_t done;
                     ll_step_finish(w, e, action, state, reward, done);
                     ll_store(d, i, w, e);
@@ -224,7 +230,8 @@ __global__ void __launch_bounds__(BLK)
 ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kSolverCap * BLK];
-    stage_tab(tab, d.k);
+    LL_HOT_DECL(BLK);
+    stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
@@ -239,8 +246,8 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
         if (q < total) {
             i = list[q];
             World w; EnvRegs e;
-            ll_load(d, i, w, e, true);
-            if (ll_step_continue(w, tab, d.k, mem, budget)) {
+            ll_load(d, i, w, e, hot, true);
+            if (ll_step_continue(w, tab, LLK(d), mem, budget)) {
                 float state[8], reward; uint32_t done;
                 ll_step_finish(w, e, io.act[i], state, reward, done);
                 ll_store(d, i, w, e);
@@ -271,7 +278,8 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     __shared__ PolyTab tab;
     // velocity constraints of the contact solver: LDS, one column per lane (31-word records: conflict-free)
     __shared__ VConstraint s_vc[kSolverCap * BLK];
-    stage_tab(tab, d.k);
+    LL_HOT_DECL(BLK);
+    stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
@@ -288,7 +296,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
         int mode = forced;
         if (list) { uint32_t ent = list[q]; i = ent & ~kWorkReset; mode = (ent & kWorkReset) ? 1 : 0; }
         World w; EnvRegs e;
-        ll_load(d, i, w, e);
+        ll_load(d, i, w, e, hot);
         float state[8];
         if (mode == 0 && !e.has_world) {
             not_reset = true;
@@ -305,7 +313,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
                 const float H = VIEWPORT_H / SCALE;
                 float height[12];
                 for (int t = 0; t < 12; ++t) height[t] = H / 8.0f;  // :1278-1280
-                ll_build_scene(w, e, tab, d.k, height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
+                ll_build_scene(w, e, tab, LLK(d), height, VIEWPORT_H / SCALE * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
                 e.step = 1u;
                 ll_observe(w.b[0], w.legs[0], w.legs[1], state);  // :1441
                 break;
@@ -317,7 +325,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
             }
             float reward, d0, d1; uint32_t done;
             ll_dispersion(d, i, e, d0, d1);
-            ll_env_step(w, e, tab, d.k, mem, action, d0, d1, state, reward, done);
+            ll_env_step(w, e, tab, LLK(d), mem, action, d0, d1, state, reward, done);
             if (need_reset) { e.episode += 1u; break; }
             if (io.rew) io.rew[i] = reward;
             if (io.done_out) io.done_out[i] = (uint8_t)done;
@@ -352,7 +360,8 @@ template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
     __shared__ PolyTab tab;
-    stage_tab(tab, d.k);
+    LL_HOT_DECL(BLK);
+    stage_tab(tab, LLK(d));
     const uint64_t total = list ? (uint64_t)*count : d.n;
     for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
@@ -363,7 +372,7 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
             V2 force; float torque;
             {
                 World w; EnvRegs e;
-                ll_load(d, i, w, e);
+                ll_load(d, i, w, e, hot);
                 ll_reset_scene(d, i, w, e, tab);
                 force = w.b[0].force; torque = w.b[0].torque;  // the initial random push (:845-849) is not a state column
                 ll_store(d, i, w, e);
@@ -423,11 +432,12 @@ __global__ void ll_export_kernel(LLDev d, uint32_t* __restrict__ blob) {
 // Testable::set_state (lunar_lander.rs:1444-1554) from blob words 0..19; counters from 25, 26
 __global__ void __launch_bounds__(kLLBlock) ll_import_kernel(LLDev d, const uint32_t* __restrict__ blob) {
     __shared__ PolyTab tab;
-    stage_tab(tab, d.k);
+    LL_HOT_DECL(kLLBlock);
+    stage_tab(tab, LLK(d));
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
     World w; EnvRegs e;
-    ll_load(d, i, w, e);
+    ll_load(d, i, w, e, hot);
     if (e.has_world) {
         float raw[18];
         for (int q = 0; q < 18; ++q) raw[q] = as_f32(blob[(uint64_t)q * d.n + i]);
@@ -442,6 +452,7 @@ struct LunarLanderEnv final : Env {
     void* base = nullptr;
     void* obs_base = nullptr;
     void* work_base = nullptr;
+    void* kdev = nullptr;
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the contact kernel
@@ -461,6 +472,7 @@ struct LunarLanderEnv final : Env {
         if (base) (void)hipFree(base);
         if (obs_base) (void)hipFree(obs_base);
         if (work_base) (void)hipFree(work_base);
+        if (kdev) (void)hipFree(kdev);
     }
 
     int init() override {
@@ -481,6 +493,9 @@ struct LunarLanderEnv final : Env {
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
         dev.bucket = bucket;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
+        MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
+        MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
+        dev.kd = static_cast<const LLConst*>(kdev);
         return MGYM_OK;
     }
 

@@ -10,6 +10,10 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#ifdef LL_HOST_STATS  // -DLL_HOST_STATS: histogram of the sub-step velocity sweeps actually run, by constraint count (tools/ll_work_stats.sh)
+static unsigned long g_toi_sweeps[13][181];
+#define LL_TOI_SWEEP_STAT(count, done) g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++
+#endif
 #include "../../modurl_gym_amd/csrc/ll_free.h"
 extern "C" {
 #include "../../oracle/oracle.h"
@@ -32,6 +36,7 @@ int main(int argc, char** argv) {
     std::vector<float> obsbuf((size_t)8 * d.n_pad, 0.0f);
     d.st = st.data(); d.obs = obsbuf.data();
     ll_make_const(d.k, -10.0f, wind, 15.0f, 1.5f);
+    d.kd = &d.k;
     PolyTab tab;
     for (int p = 0; p < 2; ++p) { tab.count[p] = d.k.poly_count[p]; for (int q = 0; q < kMaxPoly; ++q) { tab.v[p][q] = d.k.poly_v[p][q]; tab.n[p][q] = d.k.poly_n[p][q]; } }
     // oracle side
@@ -43,6 +48,7 @@ int main(int argc, char** argv) {
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
     std::vector<uint32_t> act(n);
     if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
+    uint32_t h_hot[3 * kSlots]; const CtHot hot{h_hot, 1u};  // the staged KEY / SEQ / TOI words (LDS on the GPU)
     VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
     CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
     unsigned long fast_steps = 0, general_steps = 0;
@@ -50,7 +56,7 @@ int main(int argc, char** argv) {
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
     for (uint64_t i = 0; i < n; ++i) {
         World w; EnvRegs e; float state[8];
-        ll_load(d, i, w, e);
+        ll_load(d, i, w, e, hot);
         if (deterministic) {
             float height[12]; for (int q = 0; q < 12; ++q) height[q] = (400.0f / 30.0f) / 8.0f;
             ll_build_scene(w, e, tab, d.k, height, 400.0f / 30.0f * 0.8f, false, 0.0f, 0.0f, 0, 0, true);
@@ -80,14 +86,14 @@ int main(int argc, char** argv) {
                 // time-of-impact evaluation, then one sub-step per "launch", the environment going through its
                 // mid-step columns (ll_store / ll_load with mid = true) in between, as on the GPU
                 World w; EnvRegs e;
-                ll_load(d, i, w, e);
+                ll_load(d, i, w, e, hot);
                 ll_dispersion(d, i, e, d0, d1);
                 bool fin = ll_step_begin(w, e, tab, d.k, mem, act[i], d0, d1, 0);
                 int rounds = 0;
                 while (!fin) {
                     ll_store(d, i, w, e, true);
                     World w2; EnvRegs e2;
-                    ll_load(d, i, w2, e2, true);
+                    ll_load(d, i, w2, e2, hot, true);
                     w2.overflow |= w.overflow;
                     w = w2; e = e2;
                     fin = ll_step_continue(w, tab, d.k, mem, rounds < 3 ? 1 : -1);
@@ -97,7 +103,7 @@ int main(int argc, char** argv) {
                 round_hist[rounds < 7 ? rounds : 7]++;
                 ll_step_finish(w, e, act[i], state, reward, done);
                 if (w.overflow) overflow++;
-                { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += w.ct[q].exists; if (nc > max_slots) max_slots = nc; hist[nc]++; }
+                { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += (ct_key(w.cs, q) & CK_EXISTS) ? 1 : 0; if (nc > max_slots) max_slots = nc; hist[nc]++; }
                 ll_store(d, i, w, e);
                 general_steps++;
             }
@@ -114,7 +120,7 @@ int main(int argc, char** argv) {
         }
         if (t % 2 == 0 && !deterministic) {  // masked reset of finished envs on both sides
             ora_vec_reset(ov, mask.data(), NULL, 1);
-            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e); ll_env_reset(d, i, w, e, tab, mem, state); ll_store(d, i, w, e); }
+            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e, hot); ll_env_reset(d, i, w, e, tab, mem, state); ll_store(d, i, w, e); }
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
@@ -125,6 +131,13 @@ int main(int argc, char** argv) {
     printf("time-of-impact rounds per general step (max %d):", max_rounds);
     for (int q = 0; q < 8; ++q) printf(" %lu", round_hist[q]);
     printf("\n");
+#ifdef LL_HOST_STATS
+    for (int c = 0; c < 13; ++c) {
+        unsigned long tot = 0, full = 0, le16 = 0, le48 = 0, sum = 0;
+        for (int q = 0; q <= 180; ++q) { tot += g_toi_sweeps[c][q]; sum += g_toi_sweeps[c][q] * q; if (q == 180) full += g_toi_sweeps[c][q]; if (q <= 16) le16 += g_toi_sweeps[c][q]; if (q <= 48) le48 += g_toi_sweeps[c][q]; }
+        if (tot) printf("sub-step velocity solves with %d constraints: %lu; sweeps run: mean %.1f, <=16: %.1f%%, <=48: %.1f%%, all 180: %.1f%%\n", c, tot, (double)sum / tot, 100.0 * le16 / tot, 100.0 * le48 / tot, 100.0 * full / tot);
+    }
+#endif
     ora_vec_free(ov);
     return mism ? 1 : 0;
 }

@@ -3,12 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <initializer_list>
 #include <stdint.h>
-__device__ unsigned long long g_prof[16];
-__device__ unsigned long long g_cnt[16];
-__device__ unsigned long long g_blk[8192 * 16];   // per block (wave) of the general kernel: cycles per phase, this launch
-__device__ unsigned long long g_blkcnt[8192 * 16];
+__device__ unsigned long long g_prof[24];
+__device__ unsigned long long g_cnt[24];
+__device__ unsigned long long g_blk[8192 * 24];   // per block (wave) of the general kernel: cycles per phase, this launch
+__device__ unsigned long long g_blkcnt[8192 * 24];
 #define LL_STAMP(id) do { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { unsigned long long t_ = __builtin_readcyclecounter(); \
-    if (id != 0 && id != 8) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 8192) { g_blk[blockIdx.x * 16 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 16 + id] += 1; } } s_last = t_; } } while (0)
+    if (id != 0) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 8192) { g_blk[blockIdx.x * 24 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 24 + id] += 1; } } s_last = t_; } } while (0)
 static __device__ __shared__ unsigned long long s_last;
 // sweep-state cycle diagnostics: per lane, hash the state after every sweep; record the first sweep at which the
 // hash equals the one 1..4 sweeps earlier (period p), or 180 if never.  g_cyc[kind][period 0..4][bucket of 10 sweeps]
@@ -48,30 +48,31 @@ int main(int argc, char** argv) {
     env.reset(nullptr, nullptr, true, nullptr);
     for (int t = 0; t < warm; ++t) env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);  // reach the steady mix of flight / contact
     CK(hipStreamSynchronize(env.stream));
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), z, sizeof z));
-    static unsigned long long hb[8192 * 16], hc[8192 * 16], zz[8192 * 16];
+    static unsigned long long hb[8192 * 24], hc[8192 * 24], zz[8192 * 24];
     std::vector<double> all_tot;
-    double worst_phase[16] = {0}, worst_cnt[16] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
+    double worst_phase[24] = {0}, worst_cnt[24] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
     for (int t = 0; t < steps; ++t) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), zz, sizeof zz)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blkcnt), zz, sizeof zz));
         env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);
         CK(hipStreamSynchronize(env.stream));
         CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_blk), sizeof hb)); CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_blkcnt), sizeof hc));
         int wb = -1; double wt = 0;
-        for (int b = 0; b < 8192; ++b) { double tt = 0; for (int q = 0; q < 16; ++q) tt += (double)hb[b * 16 + q]; if (tt > 0) { mean_tot += tt; nwaves++; all_tot.push_back(tt); } if (tt > wt) { wt = tt; wb = b; } }
-        if (wb >= 0) { worst_tot += wt; for (int q = 0; q < 16; ++q) { worst_phase[q] += (double)hb[wb * 16 + q]; worst_cnt[q] += (double)hc[wb * 16 + q]; } }
+        for (int b = 0; b < 8192; ++b) { double tt = 0; for (int q = 0; q < 24; ++q) tt += (double)hb[b * 24 + q]; if (tt > 0) { mean_tot += tt; nwaves++; all_tot.push_back(tt); } if (tt > wt) { wt = tt; wb = b; } }
+        if (wb >= 0) { worst_tot += wt; for (int q = 0; q < 24; ++q) { worst_phase[q] += (double)hb[wb * 24 + q]; worst_cnt[q] += (double)hc[wb * 24 + q]; } }
     }
     CK(hipStreamSynchronize(env.stream));
-    unsigned long long p[16], c[16];
+    unsigned long long p[24], c[24];
     CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_prof), sizeof p)); CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cnt), sizeof c));
-    const char* names[16] = {"", "collide", "island: DFS+integrate", "island: constraint init + joint init", "island: 180 sweeps", "island: integrate pos + position iters + sync",
-                             "island: sleep + fixture sync + find contacts", "solve_toi total tail", "", "toi: time_of_impact", "toi: advance+update+island build", "toi: integrate + sync", "toi: cs_init", "toi: position iterations (<=20)", "toi: cs_init_velocity", "toi: velocity sweeps (<=180)"};
-    double tot = 0; for (int i = 0; i < 16; ++i) tot += (double)p[i];
+    const char* names[24] = {"", "collide", "island: DFS+integrate", "island: constraint init + joint init", "island: 180 sweeps", "island: integrate pos + position iters + sync",
+                             "island: sleep + fixture sync + find contacts", "solve_toi total tail", "toi: contact order + list of evaluations (and gaps between evaluations)", "toi: time_of_impact", "toi: other contacts of the body: update + island build", "toi: integrate + sync", "toi: cs_init", "toi: position iterations (<=20)", "toi: cs_init_velocity", "toi: velocity sweeps (<=180)",
+                             "toi: list contacts, pick the earliest", "toi: advance body + update the impacting contact", "toi: fixture sync + flags + find contacts", "", "", "", "", ""};
+    double tot = 0; for (int i = 0; i < 24; ++i) tot += (double)p[i];
     printf("wave-cycles by phase over %d steps of %llu envs (general kernel only; shares, not run time):\n", steps, (unsigned long long)n);
-    for (int i = 1; i < 16; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
+    for (int i = 1; i < 24; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
     printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
-    for (int i = 1; i < 16; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
+    for (int i = 1; i < 24; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
     { unsigned long long cyc[2][5][19]; CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof cyc));
       for (int k = 0; k < 2; ++k) for (int p = 0; p < 5; ++p) { unsigned long long t = 0; for (int b = 0; b < 19; ++b) t += cyc[k][p][b]; if (!t) continue;
         printf("%s sweeps, <=2 contacts: period %d (0 = none found) n=%llu; first-detected-at histogram by 10 sweeps:", k ? "toi" : "island", p, t); for (int b = 0; b < 19; ++b) printf(" %llu", cyc[k][p][b]); printf("\n"); } }
