@@ -57,6 +57,9 @@ struct LLDev {
                         // of it in scratch (~400 B/lane), and scratch size caps the number of concurrent waves
     int auto_reset;
     int bucket;  // worklist bucketing by F_TOUCHING
+#ifdef LL_WHATIF_BUILD
+    uint32_t whatif;  // tools/ll_whatif.hip only
+#endif
 };
 
 // lunar_lander.rs:31-58
@@ -116,6 +119,9 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     w.game_over = flags & F_GAME_OVER;
     w.legs[0] = flags & F_LEG0; w.legs[1] = flags & F_LEG1;
     w.overflow = 0u; w.terrain_dirty = false;
+#ifdef LL_WHATIF_BUILD
+    w.whatif = d.whatif;
+#endif
     // the contact cache: manifold words in place, KEY / SEQ / TOI staged in `hot` for the step (ll_b2.h)
     w.cs.p = &ST(C_CONTACT); w.cs.stride = d.n_pad; w.cs.hot = hot;
     for (int s = 0; s < kSlots; ++s) {

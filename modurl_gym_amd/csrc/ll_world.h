@@ -14,6 +14,22 @@
 #define LL_DIAG_SWEEP(kind, it, ...)   // diagnostic builds hash the sweep state to look for short cycles
 #define LL_DIAG_SWEEP_END(kind)
 #endif
+// What-if switches for tools/ll_whatif.hip (NOT product code: they change the physics).  A diagnostic build defines
+// LL_WHATIF(w, bit) to test a run-time mask; the product build compiles every one of them out.
+#ifndef LL_WHATIF
+#define LL_WHATIF(w, bit) false
+#endif
+enum : uint32_t { WI_NO_COLLIDE_UPDATE = 1u, WI_NO_TOI_EVAL = 2u, WI_NO_SUBSTEPS = 4u, WI_ONE_POSITION_ITER = 8u, WI_ISLAND_SWEEPS_10 = 16u,
+                  WI_TOI_SWEEPS_12 = 32u, WI_NO_TOI_OTHER_UPDATES = 64u, WI_NO_FIND_CONTACTS = 128u };
+#ifdef LL_WHATIF_BUILD  // iteration limits of the out-of-line loops travel as an extra argument in what-if builds only
+#define LL_WI_PARAM , int wi_limit
+#define LL_WI_ARG(w, bit, normal, limited) , (LL_WHATIF(w, bit) ? (limited) : (normal))
+#define LL_WI_LIMIT(normal) wi_limit
+#else
+#define LL_WI_PARAM
+#define LL_WI_ARG(w, bit, normal, limited)
+#define LL_WI_LIMIT(normal) (normal)
+#endif
 #ifndef LL_TOI_SWEEP_STAT
 #define LL_TOI_SWEEP_STAT(count, done)  // host statistics builds count the sweeps a sub-step really ran
 #endif
@@ -42,6 +58,9 @@ struct World {
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
+#ifdef LL_WHATIF_BUILD
+    uint32_t whatif;
+#endif
 };
 
 constexpr float kW = 600.0f / 30.0f;  // VIEWPORT_W / SCALE
@@ -217,6 +236,7 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
             ct_set_key(w.cs, order[k], 0u);
             continue;
         }
+        if (LL_WHATIF(w, WI_NO_COLLIDE_UPDATE)) continue;
         Contact c = ct_get(w.cs, order[k]);
         contact_update(w, tab, c);
         ct_put(w.cs, order[k], c);
@@ -691,7 +711,7 @@ LLD float sleep_update(Body& b, float h, float minSleepTime) {
 // copied out).  The first two contact constraints ride in registers (their LDS copies could not be kept in
 // registers by the compiler: every impulse store may alias them); the rest stay in LDS.
 LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver& cs, const int* cstart, const int* ibody, int nb,
-                               bool leg1_first, const LLConst& k_in, float dt, float inv_dt) {
+                               bool leg1_first, const LLConst& k_in, float dt, float inv_dt LL_WI_PARAM) {
     Joint J0 = J0_io, J1 = J1_io;
     Vel3 vel = vel_io;
     // `k_in` points at the kernel's constant block; read through a pointer inside this loop it would be re-loaded
@@ -711,7 +731,7 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     if (cs.count > 2) { r2 = cs.vc[2 * cs.vs]; rb2 = r2.indexB; }
     if (cs.count > 3) { r3 = cs.vc[3 * cs.vs]; rb3 = r3.indexB; }
     LL_DIAG_SWEEP_BEGIN(0);
-    for (int it = 0; it < 180; ++it) {
+    for (int it = 0; it < LL_WI_LIMIT(180); ++it) {
         if (leg1_first) {
             rj_solve_velocity(J1, 1, k, vel.b0.v, vel.b0.w, vel.b2.v, vel.b2.w, dt, inv_dt);
             rj_solve_velocity(J0, 0, k, vel.b0.v, vel.b0.w, vel.b1.v, vel.b1.w, dt, inv_dt);
@@ -759,6 +779,11 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
 // (fixed point, found at once) and with a snapshot renewed at j = 1, 2, 4, 8, ... (Brent's cycle search: any period
 // is found once the snapshot lies on the cycle and the window exceeds the period).  The joints of the full island
 // never settle this way, which is why island_sweeps has no such exit.
+// What is left (tools/ll_work_stats.sh: 4 % of one-constraint and 21 % of two-constraint sub-steps run all 180
+// sweeps): slow geometric convergence of two coupled contacts, and states whose velocity has stopped moving while a
+// tangent impulse still creeps by a few ulps per sweep.  Running only the friction rows in that second case (exact:
+// the skipped rows see unchanged inputs) was built and measured — the bookkeeping cost every sweep more than the
+// few lanes it helped, and a wave still waits for its slowest lane (1.79 -> 1.91 ms per step): not kept.
 struct ToiSweepState { uint32_t w[11]; };
 LLD bool toi_state_same(const ToiSweepState& a, const ToiSweepState& b) {
     bool same = true;
@@ -766,7 +791,7 @@ LLD bool toi_state_same(const ToiSweepState& a, const ToiSweepState& b) {
     for (int q = 0; q < 11; ++q) same = same && a.w[q] == b.w[q];
     return same;
 }
-LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
+LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
     Vel vd = vd_io;
     VConstraint r0, r1;
     const bool h0 = cs.count > 0, h1 = cs.count > 1;
@@ -783,7 +808,7 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
         return st;
     };
     ToiSweepState prev = state_now(), snap = prev;
-    int done = 0, left = 180, snap_at = 0, next_snap = 1;
+    int done = 0, left = LL_WI_LIMIT(180), snap_at = 0, next_snap = 1;
     LL_DIAG_SWEEP_BEGIN(1);
     while (left > 0) {
         if (h0) cs_solve_one(r0, vd);
@@ -796,6 +821,9 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io) {
                           h0 && r0.pointCount > 1 ? r0.points[1].normalImpulse : 0.0f, h0 && r0.pointCount > 1 ? r0.points[1].tangentImpulse : 0.0f,
                           h1 ? r1.points[0].normalImpulse : 0.0f, h1 ? r1.points[0].tangentImpulse : 0.0f,
                           h1 && r1.pointCount > 1 ? r1.points[1].normalImpulse : 0.0f, h1 && r1.pointCount > 1 ? r1.points[1].tangentImpulse : 0.0f);
+#ifdef LL_TOI_SWEEP_TRACE
+            LL_TOI_SWEEP_TRACE(done, cur, cs.count);
+#endif
             if (toi_state_same(cur, prev)) break;                                                // fixed point
             if (toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
             else if (done == next_snap) { snap = cur; snap_at = done; next_snap *= 2; }
@@ -816,7 +844,7 @@ LLD void pc_solve_on(const PConstraint& pc, Pos3& pos, float& minSeparation) {
     pc_solve_one(pc, false, pb.c, pb.a, minSeparation);
     pos_put(pos, pc.indexB, pb);
 }
-LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1, const CSolver& cs, bool leg1_first, const LLConst& k_in) {
+LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1, const CSolver& cs, bool leg1_first, const LLConst& k_in LL_WI_PARAM) {
     Pos3 pos = pos_io;
     LLConst k;
     k.invMass[0] = k_in.invMass[0]; k.invMass[1] = k_in.invMass[1]; k.invI[0] = k_in.invI[0]; k.invI[1] = k_in.invI[1];
@@ -830,7 +858,7 @@ LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1,
     if (h0) q0 = cs.pc[0];
     if (h1) q1 = cs.pc[n_ps];
     bool solved = false;
-    for (int it = 0; it < 60; ++it) {
+    for (int it = 0; it < LL_WI_LIMIT(60); ++it) {
         const Pos3 before = pos;
         float minSeparation = 0.0f;
         if (h0) pc_solve_on(q0, pos, minSeparation);
@@ -944,7 +972,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
         rj_init_velocity(J1, 2, k, pos[0].a, pos[2].a, vel.b0, vel.b2, dtRatio);
     }
     LL_STAMP(3);
-    island_sweeps(J0, J1, vel, cs, cstart, ibody, nb, leg1_first, k, dt, inv_dt);
+    island_sweeps(J0, J1, vel, cs, cstart, ibody, nb, leg1_first, k, dt, inv_dt LL_WI_ARG(w, WI_ISLAND_SWEEPS_10, 180, 10));
     LL_STAMP(4);
     w.jt[0] = J0; w.jt[1] = J1;
     cs_store_impulses(cs, w);
@@ -956,7 +984,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     bool positionSolved;
     {
         Pos3 p3; p3.b0 = pos[0]; p3.b1 = pos[1]; p3.b2 = pos[2];
-        positionSolved = island_position(p3, J0, J1, cs, leg1_first, k);
+        positionSolved = island_position(p3, J0, J1, cs, leg1_first, k LL_WI_ARG(w, WI_ONE_POSITION_ITER, 60, 1));
         pos[0] = p3.b0; pos[1] = p3.b1; pos[2] = p3.b2;
     }
 
@@ -976,7 +1004,7 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     int moved[3], nm = 0;
     for (int i = 2; i >= 0; --i)  // body list order: newest first
         if (body_sync_fixtures(w, tab, i)) moved[nm++] = i;
-    find_new_contacts(w, moved, nm);
+    if (!LL_WHATIF(w, WI_NO_FIND_CONTACTS)) find_new_contacts(w, moved, nm);
 }
 
 // ---- b2World::SolveTOI ----------------------------------------------------------------------------------
@@ -1034,7 +1062,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             edge_verts(w, ck_edge(key), ev[0], ev[1]);
             float beta;
             LL_STAMP(8);
-            int state = time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
+            int state = LL_WHATIF(w, WI_NO_TOI_EVAL) ? TOI_SEPARATED : time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
             LL_STAMP(9);
             float alpha;
             if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
@@ -1051,7 +1079,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
         }
         LL_STAMP(16);
-        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha) { w.gA = gA; return true; }
+        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha || LL_WHATIF(w, WI_NO_SUBSTEPS)) { w.gA = gA; return true; }
         if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
         if (budget > 0) --budget;
 
@@ -1088,6 +1116,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             if (!(key & CK_EXISTS) || ck_body(key) != dyn || (key & CK_ISLAND)) continue;
             upd[n_upd++] = order[q];
         }
+        if (LL_WHATIF(w, WI_NO_TOI_OTHER_UPDATES)) n_upd = 0;
         for (int j = 0; j < n_upd; ++j) {
             Contact c = ct_get(w.cs, upd[j]);
             contact_update(w, tab, c);
@@ -1114,7 +1143,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         bB.sw.c0 = pos[dyn].c; bB.sw.a0 = pos[dyn].a;
         cs_init_velocity(cs, w, pos, vel);
         LL_STAMP(14);
-        toi_sweeps(cs, vd);
+        toi_sweeps(cs, vd LL_WI_ARG(w, WI_TOI_SWEEPS_12, 180, 12));
         LL_STAMP(15);
         {
             const float h = sub_dt;

@@ -12,7 +12,9 @@
 #define __forceinline__ inline
 #ifdef LL_HOST_STATS  // -DLL_HOST_STATS: histogram of the sub-step velocity sweeps actually run, by constraint count (tools/ll_work_stats.sh)
 static unsigned long g_toi_sweeps[13][181];
-#define LL_TOI_SWEEP_STAT(count, done) g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++
+#define LL_TOI_SWEEP_STAT(count, done) do { g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++; if ((done) == 180 && g_trace_left > 0) { --g_trace_left; printf("-- a sub-step that ran all 180 sweeps (%d constraints); state words after sweeps 1..180 (v.x v.y w n00 t00 n01 t01 n10 t10 n11 t11):\n", (int)(count)); for (int q_ = 0; q_ < 180; ++q_) if (q_ < 6 || q_ % 20 == 0 || q_ >= 174) { printf("   %3d:", q_ + 1); for (int z_ = 0; z_ < 11; ++z_) printf(" %08x", g_trace[q_][z_]); printf("\n"); } } } while (0)
+static unsigned g_trace[181][11]; static int g_trace_left = 6;
+#define LL_TOI_SWEEP_TRACE(done, cur, count) do { for (int z_ = 0; z_ < 11; ++z_) g_trace[(done) - 1][z_] = (cur).w[z_]; } while (0)
 #endif
 #include "../../modurl_gym_amd/csrc/ll_free.h"
 extern "C" {
