@@ -208,17 +208,19 @@ struct Contact {
 #else
 #define LL_LDS
 #endif
-struct CtHot { LL_LDS uint32_t* k; uint32_t ks; };  // staged KEY / SEQ / TOI words: word j of slot s at k[(j * kSlots + s) * ks]
+struct CtHot { LL_LDS uint32_t* k; uint32_t ks; uint32_t toi_staged; };  // staged KEY / SEQ / TOI words: word j of slot s at k[(j * kSlots + s) * ks]; TOI only if toi_staged (else in place)
 struct CtStore { uint32_t* p; uint64_t stride; CtHot hot; };
 enum : uint32_t { CK_EXISTS = 1u, CK_TOUCHING = 2u, CK_ENABLED = 4u, CK_TOIFLAG = 1u << 13, CK_ISLAND = 1u << 18 };
 constexpr uint32_t kCkRestMask = 0x1fffu;  // the key bits that persist between steps
-LLD uint32_t& ct_word(const CtStore& c, int s, int k) { return c.p[(uint64_t)(16 * s + k) * c.stride]; }  // k in 2..14
+LLD uint32_t& ct_word(const CtStore& c, int s, int k) { return c.p[(uint64_t)(16 * s + k) * c.stride]; }  // k in 2..14 (15: TOI when it is not staged)
 LLD uint32_t ct_key(const CtStore& c, int s) { return c.hot.k[(uint32_t)s * c.hot.ks]; }
 LLD void ct_set_key(const CtStore& c, int s, uint32_t v) { c.hot.k[(uint32_t)s * c.hot.ks] = v; }
 LLD uint32_t ct_seq(const CtStore& c, int s) { return c.hot.k[(uint32_t)(kSlots + s) * c.hot.ks]; }
 LLD void ct_set_seq(const CtStore& c, int s, uint32_t v) { c.hot.k[(uint32_t)(kSlots + s) * c.hot.ks] = v; }
-LLD float ct_toi(const CtStore& c, int s) { return as_f32(c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks]); }
-LLD void ct_set_toi(const CtStore& c, int s, float v) { c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks] = as_u32(v); }
+LLD float ct_toi(const CtStore& c, int s) { return as_f32(c.hot.toi_staged ? c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks] : ct_word(c, s, 15)); }
+LLD void ct_set_toi(const CtStore& c, int s, float v) {
+    if (c.hot.toi_staged) c.hot.k[(uint32_t)(2 * kSlots + s) * c.hot.ks] = as_u32(v); else ct_word(c, s, 15) = as_u32(v);
+}
 LLD int ck_body(uint32_t key) { return (int)((key >> 3) & 3u); }
 LLD int ck_edge(uint32_t key) { return (int)((key >> 5) & 15u); }
 LLD int ck_toi_count(uint32_t key) { return (int)((key >> 14) & 15u); }

@@ -55,6 +55,7 @@ struct LLDev {
     const LLConst* kd;  // the same in device memory: kernels read the constants through this pointer (scalar loads), so the
                         // by-value kernel argument never has its address taken — otherwise every lane keeps a private copy
                         // of it in scratch (~400 B/lane), and scratch size caps the number of concurrent waves
+    VConstraint* vc_far;  // workspace for the velocity constraints that do not fit a block's LDS: [kSolverCap - near][contact-kernel lanes]
     int auto_reset;
     int bucket;  // worklist bucketing by F_TOUCHING
 #ifdef LL_WHATIF_BUILD
@@ -127,7 +128,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     for (int s = 0; s < kSlots; ++s) {
         ct_set_key(w.cs, s, ST(C_CONTACT + 16 * s + 0));
         ct_set_seq(w.cs, s, ST(C_CONTACT + 16 * s + 1));
-        if (mid) ct_set_toi(w.cs, s, as_f32(ST(C_CONTACT + 16 * s + 15)));
+        if (mid && hot.toi_staged) ct_set_toi(w.cs, s, as_f32(ST(C_CONTACT + 16 * s + 15)));
     }
     e.prev_shaping = as_f32(ST(C_PREV));
     e.prev_some = flags & F_PREV_SOME;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World
         ST(C_CONTACT + 16 * s + 0) = key;
         if (!(key & CK_EXISTS)) continue;
         ST(C_CONTACT + 16 * s + 1) = ct_seq(w.cs, s);
-        if (mid) ST(C_CONTACT + 16 * s + 15) = as_u32(ct_toi(w.cs, s));
+        if (mid && w.cs.hot.toi_staged) ST(C_CONTACT + 16 * s + 15) = as_u32(ct_toi(w.cs, s));
         ++ncont;
         touching |= (key & CK_TOUCHING) ? 1u : 0u;
     }

@@ -247,12 +247,16 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
 // Constraint storage is supplied by the caller: on the GPU the velocity constraints live in LDS, one
 // column per lane (element i of lane l at vc[i * stride], stride = 64), the position constraints in local
 // memory; the host test passes plain arrays with stride 1.
-struct CSolverMem { VConstraint* vc; int vc_stride; PConstraint* pc; int pc_stride; int cap; };
+// The first `vc_near` velocity constraints of a lane live in `vc` (LDS), the rest — rarely more than a few exist —
+// in `vc_far` (a global workspace): a 64-lane block affords 5 constraints per lane in LDS at four blocks per CU.
+struct CSolverMem { VConstraint* vc; int vc_stride; int vc_near; VConstraint* vc_far; int vc_far_stride; PConstraint* pc; int pc_stride; int cap; };
 struct CSolver {
     VConstraint* vc; int vs;
+    int nl; VConstraint* vo; int vos;  // constraint i >= nl is vo[(i - nl) * vos]
     PConstraint* pc; int ps;
     int count;
 };
+LLD VConstraint& cs_vc(const CSolver& s, int i) { return i < s.nl ? s.vc[i * s.vs] : s.vo[(i - s.nl) * s.vos]; }
 // body-indexed access to three register-resident velocity / position records
 struct Vel3 { Vel b0, b1, b2; };
 LLD Vel vel_get(const Vel3& v, int i) {
@@ -312,14 +316,14 @@ LLD bool pos_same(const Pos& a, const Pos& b) {
 }
 
 LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
-    s.vc = mem.vc; s.vs = mem.vc_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
+    s.vc = mem.vc; s.vs = mem.vc_stride; s.nl = mem.vc_near; s.vo = mem.vc_far; s.vos = mem.vc_far_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
     if (count > mem.cap) { w.overflow |= 2u; count = mem.cap; }
     s.count = count;
     for (int i = 0; i < count; ++i) {
         const Contact contact = ct_get(w.cs, slots[i]);
         const Manifold& manifold = contact.m;
         const int t = poly_of(contact.body);
-        VConstraint& vc = s.vc[i * s.vs];
+        VConstraint& vc = cs_vc(s, i);
         vc.friction = k.friction[t];
         vc.indexB = contact.body;
         vc.invMassB = k.invMass[t]; vc.invIB = k.invI[t];
@@ -350,7 +354,7 @@ LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, 
 // zero when vRel < -threshold), which only ever enters `vn - velocityBias` and is therefore left at 0.
 LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel3& vel) {
     for (int i = 0; i < s.count; ++i) {
-        VConstraint& vc = s.vc[i * s.vs];
+        VConstraint& vc = cs_vc(s, i);
         const PConstraint& pc = s.pc[i * s.ps];
         const Manifold manifold = ct_get(w.cs, vc.slot).m;
         const float mB = vc.invMassB, iB = vc.invIB;
@@ -399,7 +403,7 @@ LLD void cs_init_velocity(CSolver& s, const World& w, const Pos* pos, const Vel3
 
 LLD void cs_warm_start(const CSolver& s, Vel3& vel) {  // b2ContactSolver::WarmStart
     for (int i = 0; i < s.count; ++i) {
-        const VConstraint& vc = s.vc[i * s.vs];
+        const VConstraint& vc = cs_vc(s, i);
         const float mB = vc.invMassB, iB = vc.invIB;
         const Vel velB = vel_get(vel, vc.indexB);
         V2 vB = velB.v; float wB = velB.w;
@@ -489,7 +493,7 @@ LLD void cs_solve_one(VConstraint& vc, Vel& velB) {
 // ... for constraints [i0, i1), all of which act on the SAME dynamic body (island contacts are grouped by body
 // in DFS order), whose velocity lives in the caller's registers
 LLD void cs_solve_velocity_range(CSolver& s, int i0, int i1, Vel& velB) {
-    for (int i = i0; i < i1; ++i) cs_solve_one(s.vc[i * s.vs], velB);
+    for (int i = i0; i < i1; ++i) cs_solve_one(cs_vc(s, i), velB);
 }
 LLD void cs_solve_one_on(VConstraint& vc, int body, Vel3& vel) {
     Vel vb = vel_pick(vel, body);
@@ -499,7 +503,7 @@ LLD void cs_solve_one_on(VConstraint& vc, int body, Vel3& vel) {
 
 LLD void cs_store_impulses(const CSolver& s, World& w) {  // b2ContactSolver::StoreImpulses
     for (int i = 0; i < s.count; ++i) {
-        const VConstraint& vc = s.vc[i * s.vs];
+        const VConstraint& vc = cs_vc(s, i);
         for (int j = 0; j < vc.pointCount; ++j) {
             ct_word(w.cs, vc.slot, 8 + 4 * j) = as_u32(vc.points[j].normalImpulse);
             ct_word(w.cs, vc.slot, 9 + 4 * j) = as_u32(vc.points[j].tangentImpulse);

@@ -39,8 +39,9 @@ constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no in
 #define LL_SOLVER_CAP 9
 #endif
 constexpr int kSolverCap = LL_SOLVER_CAP;
+constexpr int kVcNear64 = 4;  // of those, kept in LDS by a 64-lane block of the contact kernel (4 blocks per CU); the rest in LLDev::vc_far
 // the staged KEY / SEQ / TOI words of the contact cache (ll_b2.h CtHot): one LDS column per lane of the block
-#define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ)}
+#define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ), 1u}
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 // Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
 //   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
@@ -163,13 +164,17 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
+    // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
+    constexpr int kVcNear = BLK > 32 ? kVcNear64 : kSolverCap;
     __shared__ PolyTab tab;
-    __shared__ VConstraint s_vc[kSolverCap * BLK];
-    LL_HOT_DECL(BLK);
+    __shared__ VConstraint s_vc[kVcNear * BLK];
+    __shared__ uint32_t s_hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
+    const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)BLK, BLK > 32 ? 0u : 1u};  // 64-lane blocks: KEY and SEQ only
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc_far = d.vc_far + ((uint64_t)blockIdx.x * BLK + threadIdx.x); mem.vc_far_stride = (int)(gridDim.x * BLK);
     bool not_reset = false;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
@@ -234,7 +239,7 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = kSolverCap; mem.vc_far = nullptr; mem.vc_far_stride = 0; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
     const uint32_t* list = d.work_list + (uint64_t)(L_TOI0 + round) * d.n_pad;
@@ -282,7 +287,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = kSolverCap; mem.vc_far = nullptr; mem.vc_far_stride = 0; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     bool not_reset = false;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
@@ -453,9 +458,10 @@ struct LunarLanderEnv final : Env {
     void* obs_base = nullptr;
     void* work_base = nullptr;
     void* kdev = nullptr;
+    void* vc_far_base = nullptr;
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
-    int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 32;  // lanes per block of the contact kernel
+    int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 0;   // lanes per block of the contact kernel; 0: by population (init)
     int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
     // Launch structure of the contact path.  Measured on MI355X (profiles/r02_lunarlander/tune_launch_structure.txt), 262 144
     // envs, ms per step: whole world.step in the contact kernel, envs in index order 1.96 (default) | the same with
@@ -473,9 +479,16 @@ struct LunarLanderEnv final : Env {
         if (obs_base) (void)hipFree(obs_base);
         if (work_base) (void)hipFree(work_base);
         if (kdev) (void)hipFree(kdev);
+        if (vc_far_base) (void)hipFree(vc_far_base);
     }
 
     int init() override {
+        // Contact-kernel block size.  32-lane blocks (all 9 velocity constraints per lane in LDS) give the shortest waves:
+        // best while the whole worklist is co-resident (1.82 vs 1.95 ms per step at 262 144 envs).  Beyond that the kernel is
+        // bound by wave slots — one 512-register wave per SIMD, four blocks per CU by LDS — and 64-lane blocks (4 constraints
+        // per lane in LDS, the rest in LLDev::vc_far) carry twice the environments per slot: 2.37 vs 2.91 ms at 524 288 envs,
+        // 3.97 vs 4.82 at 1 Mi, 6.94 vs 8.57 at 2 Mi (profiles/r02_lunarlander/block_size_by_population.txt).
+        if (gen_block == 0) gen_block = n >= 393216 ? 64 : 32;
         obs_dim = 8;
         state_cols = 27;
         MGYM_HIP(hipMalloc(&base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
@@ -496,6 +509,9 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
         dev.kd = static_cast<const LLConst*>(kdev);
+        // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
+        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNear64) * work_grid().x * 64 * sizeof(VConstraint)));
+        dev.vc_far = static_cast<VConstraint*>(vc_far_base);
         return MGYM_OK;
     }
 

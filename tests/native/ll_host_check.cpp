@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
     const int steps = argc > 2 ? atoi(argv[2]) : 300;
     const int wind = argc > 3 ? atoi(argv[3]) : 0;
     const int deterministic = argc > 4 ? atoi(argv[4]) : 0;
+    const unsigned toi_staged = argc > 5 ? (unsigned)atoi(argv[5]) : 1u;  // 0: the TOI word of the contact cache stays in place (64-lane blocks)
     const uint64_t seed = 77;
     // product side: SoA state exactly as the kernels keep it
     LLDev d;
@@ -50,9 +51,9 @@ int main(int argc, char** argv) {
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
     std::vector<uint32_t> act(n);
     if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
-    uint32_t h_hot[3 * kSlots]; const CtHot hot{h_hot, 1u};  // the staged KEY / SEQ / TOI words (LDS on the GPU)
+    uint32_t h_hot[3 * kSlots]; const CtHot hot{h_hot, 1u, toi_staged};  // the staged KEY / SEQ / TOI words (LDS on the GPU)
     VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
-    CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
+    CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.vc_near = kSlots; mem0.vc_far = nullptr; mem0.vc_far_stride = 0; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
     unsigned long fast_steps = 0, general_steps = 0;
     int max_slots = 0, max_rounds = 0; unsigned long hist[kSlots + 1] = {0}, round_hist[8] = {0};
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
@@ -68,7 +69,8 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; if (!closef(state[q], oobs[q * n + i])) { if (mism < 10) printf("reset env %lu obs[%d] %.9g vs %.9g\n", (unsigned long)i, q, state[q], oobs[q * n + i]); mism++; } }
     }
     VConstraint h_vc[kSlots]; PConstraint h_pc[kSlots];
-    CSolverMem mem; mem.vc = h_vc; mem.vc_stride = 1; mem.pc = h_pc; mem.pc_stride = 1; mem.cap = kSlots;
+    VConstraint h_vc_far[kSlots];  // constraints 4.. go through the far (global workspace) path here, as in 64-lane blocks on the GPU
+    CSolverMem mem; mem.vc = h_vc; mem.vc_stride = 1; mem.vc_near = 4; mem.vc_far = h_vc_far; mem.vc_far_stride = 1; mem.pc = h_pc; mem.pc_stride = 1; mem.cap = kSlots;
     uint32_t rs = 12345;
     for (int t = 0; t < steps; ++t) {
         for (uint64_t i = 0; i < n; ++i) { rs = rs * 1664525u + 1013904223u; act[i] = (rs >> 16) & 3u; }

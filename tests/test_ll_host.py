@@ -30,9 +30,11 @@ def ll_host():
     return _build("ll_host_check.cpp", "ll_host_check", [f"-L{odir}", "-loracle", f"-Wl,-rpath,{odir}"])
 
 
-@pytest.mark.parametrize("n,steps,wind,det", [(64, 300, 0, 1), (256, 400, 0, 0), (256, 400, 1, 0)])
-def test_kernel_source_matches_oracle_on_cpu(ll_host, n, steps, wind, det):
-    r = subprocess.run([ll_host, str(n), str(steps), str(wind), str(det)], capture_output=True, text=True)
+@pytest.mark.parametrize("n,steps,wind,det,toi_staged", [(64, 300, 0, 1, 1), (256, 400, 0, 0, 1), (256, 400, 1, 0, 1), (256, 300, 1, 0, 0)])
+def test_kernel_source_matches_oracle_on_cpu(ll_host, n, steps, wind, det, toi_staged):
+    """toi_staged = 0: the contact cache's TOI word stays in its column (the 64-lane blocks' layout); in every case the
+    velocity constraints beyond the fourth go through the far-workspace path."""
+    r = subprocess.run([ll_host, str(n), str(steps), str(wind), str(det), str(toi_staged)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     m = re.search(r"mismatches=(\d+) exact_words=(\d+)/(\d+) episodes_done=(\d+) overflow=(\d+)", r.stdout)
     assert m, r.stdout
