@@ -180,7 +180,11 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
     uint32_t finished = 0;
     const uint32_t* list = d.work_list + (uint64_t)L_GENERAL * d.n_pad;
     const uint64_t c0 = d.work_count[L_GENERAL], c1 = d.work_count[L_GENERAL_T];
-    const uint64_t c0_up = (c0 + BLK - 1) / BLK * BLK;  // the touching bucket starts at a block boundary
+    // bucket 1: the touching bucket starts at a block boundary (waves of one kind); bucket 2: the touching envs — the ones
+    // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
+    // of the first q entries floor(q * c1 / total) come from the touching list
+    const bool spread = d.bucket == 2;
+    const uint64_t c0_up = spread ? c0 : (c0 + BLK - 1) / BLK * BLK;
     const uint64_t total = c0_up + c1;
     for (uint64_t q0 = (uint64_t)blockIdx.x * BLK; q0 < total; q0 += (uint64_t)gridDim.x * BLK) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
@@ -188,7 +192,12 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
         if (have) {
-            i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
+            if (spread) {
+                const uint64_t h0 = q * c1 / total, h1 = (q + 1) * c1 / total;
+                i = h1 > h0 ? list[d.n_pad - 1u - h0] : list[q - h0];
+            } else {
+                i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
+            }
             World w; EnvRegs e;
             ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920

@@ -11,7 +11,7 @@
 #define __host__
 #define __forceinline__ inline
 #ifdef LL_HOST_STATS  // -DLL_HOST_STATS: histogram of the sub-step velocity sweeps actually run, by constraint count (tools/ll_work_stats.sh)
-static unsigned long g_toi_sweeps[13][181];
+static unsigned long g_toi_sweeps[13][181], g_rounds_by_touch[2][6], g_rounds_by_ncont[9][6];
 #define LL_TOI_SWEEP_STAT(count, done) do { g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++; if ((done) == 180 && g_trace_left > 0) { --g_trace_left; printf("-- a sub-step that ran all 180 sweeps (%d constraints); state words after sweeps 1..180 (v.x v.y w n00 t00 n01 t01 n10 t10 n11 t11):\n", (int)(count)); for (int q_ = 0; q_ < 180; ++q_) if (q_ < 6 || q_ % 20 == 0 || q_ >= 174) { printf("   %3d:", q_ + 1); for (int z_ = 0; z_ < 11; ++z_) printf(" %08x", g_trace[q_][z_]); printf("\n"); } } } while (0)
 static unsigned g_trace[181][11]; static int g_trace_left = 6;
 #define LL_TOI_SWEEP_TRACE(done, cur, count) do { for (int z_ = 0; z_ < 11; ++z_) g_trace[(done) - 1][z_] = (cur).w[z_]; } while (0)
@@ -90,6 +90,10 @@ int main(int argc, char** argv) {
                 // time-of-impact evaluation, then one sub-step per "launch", the environment going through its
                 // mid-step columns (ll_store / ll_load with mid = true) in between, as on the GPU
                 World w; EnvRegs e;
+#ifdef LL_HOST_STATS
+                const uint32_t flags0 = d.st[(uint64_t)C_FLAGS * d.n_pad + i];
+                const int touching0 = (flags0 & F_TOUCHING) ? 1 : 0, ncont0 = (int)((flags0 >> F_NCONTACT_SHIFT) & 15u);
+#endif
                 ll_load(d, i, w, e, hot);
                 ll_dispersion(d, i, e, d0, d1);
                 bool fin = ll_step_begin(w, e, tab, d.k, mem, act[i], d0, d1, 0);
@@ -105,6 +109,9 @@ int main(int argc, char** argv) {
                 }
                 if (rounds > max_rounds) max_rounds = rounds;
                 round_hist[rounds < 7 ? rounds : 7]++;
+#ifdef LL_HOST_STATS
+                g_rounds_by_touch[touching0][rounds < 5 ? rounds : 5]++; g_rounds_by_ncont[ncont0 < 8 ? ncont0 : 8][rounds < 5 ? rounds : 5]++;
+#endif
                 ll_step_finish(w, e, act[i], state, reward, done);
                 if (w.overflow) overflow++;
                 { int nc = 0; for (int q = 0; q < kSlots; ++q) nc += (ct_key(w.cs, q) & CK_EXISTS) ? 1 : 0; if (nc > max_slots) max_slots = nc; hist[nc]++; }
@@ -136,6 +143,10 @@ int main(int argc, char** argv) {
     for (int q = 0; q < 8; ++q) printf(" %lu", round_hist[q]);
     printf("\n");
 #ifdef LL_HOST_STATS
+    for (int tq = 0; tq < 2; ++tq) { unsigned long tot = 0, sum = 0; for (int r = 0; r < 6; ++r) { tot += g_rounds_by_touch[tq][r]; sum += g_rounds_by_touch[tq][r] * r; }
+        printf("general steps that start %s a touching contact: %lu; sub-steps 0/1/2/3/4/5+:", tq ? "with" : "without", tot); for (int r = 0; r < 6; ++r) printf(" %.1f%%", 100.0 * g_rounds_by_touch[tq][r] / (tot ? tot : 1)); printf("  mean %.2f\n", (double)sum / (tot ? tot : 1)); }
+    for (int c = 0; c < 9; ++c) { unsigned long tot = 0, sum = 0; for (int r = 0; r < 6; ++r) { tot += g_rounds_by_ncont[c][r]; sum += g_rounds_by_ncont[c][r] * r; }
+        if (tot) { printf("general steps that start with %d cached contacts: %lu; sub-steps 0/1/2/3/4/5+:", c, tot); for (int r = 0; r < 6; ++r) printf(" %.1f%%", 100.0 * g_rounds_by_ncont[c][r] / tot); printf("  mean %.2f\n", (double)sum / tot); } }
     for (int c = 0; c < 13; ++c) {
         unsigned long tot = 0, full = 0, le16 = 0, le48 = 0, sum = 0;
         for (int q = 0; q <= 180; ++q) { tot += g_toi_sweeps[c][q]; sum += g_toi_sweeps[c][q] * q; if (q == 180) full += g_toi_sweeps[c][q]; if (q <= 16) le16 += g_toi_sweeps[c][q]; if (q <= 48) le48 += g_toi_sweeps[c][q]; }
