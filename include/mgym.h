@@ -115,7 +115,9 @@ int mgym_default_config(int kind, mgym_config *cfg);
 int mgym_create(const mgym_config *cfg, mgym_env **out);
 int mgym_destroy(mgym_env *env);
 
-/* Launch stream (hipStream_t).  Default: a stream created by the engine. */
+/* Launch stream (hipStream_t).  Default: a stream created by the engine.  Every call is ordered on this stream as far
+ * as the caller can tell.  A LunarLander step may run part of its kernels on an engine-owned helper stream, forked
+ * from and joined back into this stream by events inside the call (so it is also capturable by mgym_graph_begin). */
 int mgym_set_stream(mgym_env *env, void *hip_stream);
 void *mgym_get_stream(mgym_env *env);
 

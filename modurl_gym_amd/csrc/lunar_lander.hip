@@ -48,9 +48,10 @@ constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kW
 //                the front (count L_GENERAL), envs with one from the back (count L_GENERAL_T), so the waves of the
 //                worklist kernel hold environments of one kind (180 joint-only sweeps vs. sweeps with contact constraints).
 //   L_RESET      finished envs to reset (register-only fast path); L_RESET_SLOW: resets the fast path declined
+//   L_LATE       overlapped launch order only: envs the free-flight kernel had to decline (a contact would be created)
 //   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
 constexpr int kToiRounds = 4;
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_TOI0 = 4, L_COUNT = L_TOI0 + kToiRounds };
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_TOI0 = 5, L_COUNT = L_TOI0 + kToiRounds };
 
 struct LLIo {
     const uint32_t* act;
@@ -91,10 +92,51 @@ __device__ __forceinline__ void ll_push_back(const LLDev& d, int which_list, int
     if (want) d.work_list[(uint64_t)which_list * d.n_pad + (d.n_pad - 1u - (base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))))] = entry;
 }
 
+// block-aggregated append for kernels whose every wave appends (ll_classify_kernel): ONE atomic per block and list — thousands
+// of per-wave atomics on one counter serialise at ~11 ns each.  All threads of the block must call it (it synchronises);
+// `s_cnt` is block-shared scratch for (blockDim.x / 64 + 1) words.
+__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt) {
+    const unsigned long long mask = __ballot(want);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();  // s_cnt may still be read by the previous call
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; ++w) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+        s_cnt[nw] = tot ? atomicAdd(d.work_count + which, tot) : 0u;
+    }
+    __syncthreads();
+    if (want) d.work_list[(uint64_t)which * d.n_pad + s_cnt[nw] + s_cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+}
+
 // done-mask reduction for mgym_episode_count: ballot + popcount per wave pass, one fire-and-forget atomic per wave at the end
 __device__ __forceinline__ void ll_flush_done(const LLDev& d, uint32_t finished) {
     if ((threadIdx.x & 63) == 0 && finished)
         atomicAdd(d.done_count + ((blockIdx.x + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
+}
+
+// Overlapped launch order, stage 0.  Which envs need the contact path is known from the flag word alone (a world exists,
+// and a body sleeps or a contact is cached), so that list is built up front and the contact kernel runs BESIDE the
+// free-flight kernel instead of behind it.  The class of every env is also written to LLDev::env_class: the two kernels
+// run at the same time, and an env the contact kernel has already finished may look free-flight-eligible by its new flag
+// word — the free-flight kernel goes by the class byte, which nothing changes during the step.
+__global__ void __launch_bounds__(1024)
+ll_classify_kernel(LLDev d) {
+    __shared__ uint32_t s_cnt[17];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // block-uniform trip count
+        const uint64_t i = base + threadIdx.x;
+        bool to_general = false, touching = false;
+        if (i < d.n) {
+            const uint32_t flags = ST(C_FLAGS);
+            to_general = (flags & F_HAS_WORLD) && !ll_free_eligible(flags);
+            touching = d.bucket && (flags & F_TOUCHING);
+            d.env_class[i] = to_general ? 1 : 0;
+        }
+        ll_push_block(d, L_GENERAL, to_general && !touching, (uint32_t)i, s_cnt);
+        if (d.bucket) ll_push_back(d, L_GENERAL, L_GENERAL_T, to_general && touching, (uint32_t)i);
+    }
 }
 
 // Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
@@ -110,7 +152,8 @@ ll_free_kernel(LLDev d, LLIo io) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // wave-uniform trip count
         const uint64_t i = base + threadIdx.x;
-        const bool valid = i < d.n;
+        // overlapped order: envs of the contact class are being stepped (or were, already) by the contact kernel beside us
+        const bool valid = i < d.n && !(d.split && d.env_class[i]);
         bool to_general = false, to_reset = false, is_done = false, touching = false;
         if (valid) {
             const uint32_t flags = ST(C_FLAGS);
@@ -140,8 +183,12 @@ ll_free_kernel(LLDev d, LLIo io) {
                 }
             }
         }
-        ll_push(d, L_GENERAL, to_general && !touching, (uint32_t)i);
-        ll_push_back(d, L_GENERAL, L_GENERAL_T, to_general && touching, (uint32_t)i);
+        if (d.split) {
+            ll_push(d, L_LATE, to_general, (uint32_t)i);  // declined by the fast path: a short contact launch of its own
+        } else {
+            ll_push(d, L_GENERAL, to_general && !touching, (uint32_t)i);
+            ll_push_back(d, L_GENERAL, L_GENERAL_T, to_general && touching, (uint32_t)i);
+        }
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
         finished += (uint32_t)__popcll(__ballot(is_done));
     }
@@ -163,7 +210,7 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // the rest go, with their unfinished SolveTOI state in the C_MID columns, onto L_TOI0 for ll_toi_kernel.
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
-ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
+ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
     constexpr int kVcNear = BLK > 32 ? kVcNear64 : kSolverCap;
     __shared__ PolyTab tab;
@@ -178,8 +225,8 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget) {
     bool not_reset = false;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
-    const uint32_t* list = d.work_list + (uint64_t)L_GENERAL * d.n_pad;
-    const uint64_t c0 = d.work_count[L_GENERAL], c1 = d.work_count[L_GENERAL_T];
+    const uint32_t* list = d.work_list + (uint64_t)which * d.n_pad;  // L_GENERAL (two-ended) or L_LATE
+    const uint64_t c0 = d.work_count[which], c1 = which == L_GENERAL ? d.work_count[L_GENERAL_T] : 0u;
     // bucket 1: the touching bucket starts at a block boundary (waves of one kind); bucket 2: the touching envs — the ones
     // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
     // of the first q entries floor(q * c1 / total) come from the touching list
@@ -468,6 +515,10 @@ struct LunarLanderEnv final : Env {
     void* work_base = nullptr;
     void* kdev = nullptr;
     void* vc_far_base = nullptr;
+    hipStream_t aux = nullptr;          // helper stream of the overlapped launch order
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint8_t* env_class = nullptr;       // [n] class of each env for this step (ll_classify_kernel): 0 free flight, 1 contact path
+    int overlap = getenv("MGYM_LL_OVERLAP") ? atoi(getenv("MGYM_LL_OVERLAP")) : -1;  // 1 (default): contact kernel beside the free-flight kernel (see step()); 0: one after the other
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 0;   // lanes per block of the contact kernel; 0: by population (init)
@@ -489,15 +540,25 @@ struct LunarLanderEnv final : Env {
         if (work_base) (void)hipFree(work_base);
         if (kdev) (void)hipFree(kdev);
         if (vc_far_base) (void)hipFree(vc_far_base);
+        if (aux) (void)hipStreamDestroy(aux);
+        if (env_class) (void)hipFree(env_class);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 
     int init() override {
-        // Contact-kernel block size.  32-lane blocks (all 9 velocity constraints per lane in LDS) give the shortest waves:
-        // best while the whole worklist is co-resident (1.82 vs 1.95 ms per step at 262 144 envs).  Beyond that the kernel is
-        // bound by wave slots — one 512-register wave per SIMD, four blocks per CU by LDS — and 64-lane blocks (4 constraints
-        // per lane in LDS, the rest in LLDev::vc_far) carry twice the environments per slot: 2.37 vs 2.91 ms at 524 288 envs,
-        // 3.97 vs 4.82 at 1 Mi, 6.94 vs 8.57 at 2 Mi (profiles/r02_lunarlander/block_size_by_population.txt).
-        if (gen_block == 0) gen_block = n >= 393216 ? 64 : 32;
+        // Contact-kernel block size and launch order (profiles/r02_lunarlander/population_block_overlap_matrix.txt, ms per step,
+        // 32-lane / 64-lane blocks, sequential -> overlapped order):
+        //     131 072 envs  1.58 -> 1.43 / 1.67 -> 1.54        524 288 envs  2.90 -> 2.71 / 2.38 -> 1.87
+        //     262 144 envs  1.82 -> 1.52 / 1.94 -> 1.71      1 048 576 envs  4.85 -> 4.91 / 3.99 -> 3.66
+        //     393 216 envs  2.55 -> 2.15 / 2.20 -> 1.79      2 097 152 envs  8.64 -> 8.71 / 7.02 -> 6.78
+        // 32-lane blocks (all 9 velocity constraints per lane in LDS) give the shortest waves: best while the whole
+        // worklist is co-resident.  Beyond that the kernel is bound by wave slots — one 512-register wave per SIMD, four
+        // blocks per CU by LDS — and 64-lane blocks (4 constraints per lane in LDS, the rest in LLDev::vc_far) carry twice
+        // the environments per slot.  The overlapped order (contact kernel beside the free-flight kernel, see step()) pays
+        // at every size once the blocks are chosen this way.
+        if (gen_block == 0) gen_block = n >= 327680 ? 64 : 32;
+        if (overlap < 0) overlap = 1;
         obs_dim = 8;
         state_cols = 27;
         MGYM_HIP(hipMalloc(&base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
@@ -521,6 +582,13 @@ struct LunarLanderEnv final : Env {
         // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
         MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNear64) * work_grid().x * 64 * sizeof(VConstraint)));
         dev.vc_far = static_cast<VConstraint*>(vc_far_base);
+        MGYM_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        MGYM_HIP(hipMalloc((void**)&env_class, n_pad));
+        MGYM_HIP(hipMemsetAsync(env_class, 0, n_pad, stream));
+        dev.env_class = env_class;
+        MGYM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        MGYM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        dev.split = 0;
         return MGYM_OK;
     }
 
@@ -563,6 +631,23 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
+    void launch_free(hipStream_t s, const LLDev& d, const LLIo& io) {
+        switch (free_occ) {
+        case 1: hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, s, d, io); break;
+        case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, s, d, io); break;
+        default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, s, d, io); break;
+        }
+    }
+    void launch_contact(hipStream_t s, int block, unsigned gb, const LLDev& d, const LLIo& io, int toi_budget, int which) {
+        switch (block) {
+        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, s, d, io, toi_budget, which); break;
+        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, s, d, io, toi_budget, which); break;
+        case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(40), 0, s, d, io, toi_budget, which); break;
+        case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(48), 0, s, d, io, toi_budget, which); break;
+        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, s, d, io, toi_budget, which); break;
+        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, s, d, io, toi_budget, which); break;
+        }
+    }
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
         if (n == 0) return MGYM_OK;
         LLIo io{static_cast<const uint32_t*>(actions), obs_out, reward, done, trunc};
@@ -572,21 +657,26 @@ struct LunarLanderEnv final : Env {
             return MGYM_OK;
         }
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
-        switch (free_occ) {
-        case 1: hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
-        case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
-        default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, stream, dev, io); break;
-        }
-        // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
-        // grid-stride inside: the list lengths only exist on the device)
         const unsigned gb = (unsigned)(((uint64_t)work_grid().x * 64 + gen_block - 1) / gen_block);
-        switch (gen_block) {
-        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
-        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
-        case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(40), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
-        case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(48), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
-        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
-        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, stream, dev, io, toi_rounds > 0 ? 0 : -1); break;
+        if (overlap && toi_rounds == 0) {
+            // Overlapped order (see ll_classify_kernel): the contact kernel starts at once on the caller's stream; beside it,
+            // on the helper stream, the free-flight kernel over everyone else, followed by a short contact launch for the
+            // envs it declined (a contact was created at the end of their step).  Stream-ordered for the caller and
+            // capturable (fork / join by events).  262 144 envs: 1.82 -> 1.52 ms per step (table in init()).
+            LLDev sd = dev; sd.split = 1;
+            hipLaunchKernelGGL(ll_classify_kernel, dim3((unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256)), dim3(1024), 0, stream, sd);
+            MGYM_HIP(hipEventRecord(ev_fork, stream));
+            launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
+            MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            launch_free(aux, sd, io);
+            launch_contact(aux, 32, work_grid().x < 256 ? work_grid().x : 256, sd, io, -1, L_LATE);
+            MGYM_HIP(hipEventRecord(ev_join, aux));
+            MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+        } else {
+            launch_free(stream, dev, io);
+            // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
+            // grid-stride inside: the list lengths only exist on the device)
+            launch_contact(stream, gen_block, gb, dev, io, toi_rounds > 0 ? 0 : -1, L_GENERAL);
         }
         for (int r = 0; r < toi_rounds; ++r) {
             unsigned g = (work_grid().x * (64 / toi_block)) >> (r + 1);
