@@ -26,7 +26,7 @@ def sha16(files):
 def main():
     rnd = sys.argv[1]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    out = {}
+    out = json.load(open(path)) if os.path.exists(path) else {}   # records of the other workloads stay
     for kv in sys.argv[2:]:
         key, tag = kv.split("=")
         fam = key.split(":")[0].replace("_cont", "")
@@ -44,19 +44,21 @@ def main():
         else:
             lanes64 = active = 0.0
             per = {}
+            steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_free_kernel" in k] + [1])  # one free-flight launch per step
             for k, v in summ.items():
                 if "mgym::ll_" not in k or "pmc" not in v or "f32_flop_per_launch_lanes64" not in v["derived"] or v.get("calls", 0) < 10:
                     continue   # (one-shot kernels — the initial reset of the whole population — are not part of a step)
                 d = v["derived"]
-                f64 = d["f32_flop_per_launch_lanes64"]
+                per_step = v.get("calls", steps) / steps   # the contact kernel runs twice per step in the overlapped order
+                f64 = d["f32_flop_per_launch_lanes64"] * per_step
                 act = f64 * d.get("mean_active_lanes_per_valu_inst", 64.0) / 64.0
                 lanes64 += f64
                 active += act
-                per[k.split("(")[0].replace("void mgym::", "")] = {"avg_ns": v.get("avg_ns_steady"), "f32_flop_lanes64": f64, "f32_flop_active_lanes": act,
+                per[k.split("(")[0].replace("void mgym::", "")] = {"avg_ns": v.get("avg_ns_steady"), "launches_per_step": per_step, "f32_flop_lanes64": f64, "f32_flop_active_lanes": act,
                                                                    "mean_active_lanes": d.get("mean_active_lanes_per_valu_inst"),
                                                                    "valu_busy_share_of_wave_cycles": d.get("valu_active_share_of_wave_cycles")}
             rec.update(f32_flop_per_step_lanes64=lanes64, f32_flop_per_step_active_lanes=active, kernels=per,
-                       note="one launch of each kernel per step; flop = 64 x (2 x SQ_INSTS_VALU_FMA_F32 + MUL_F32 + ADD_F32), weighted by "
+                       note="per step (launches_per_step x the per-launch average; the kernels of one step overlap in time); flop = 64 x (2 x SQ_INSTS_VALU_FMA_F32 + MUL_F32 + ADD_F32), weighted by "
                             "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (mean active lanes per VALU instruction) for the active-lane figure")
         out[key] = rec
     json.dump(out, open(path, "w"), indent=1)
