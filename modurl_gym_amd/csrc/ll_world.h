@@ -20,7 +20,8 @@
 #define LL_WHATIF(w, bit) false
 #endif
 enum : uint32_t { WI_NO_COLLIDE_UPDATE = 1u, WI_NO_TOI_EVAL = 2u, WI_NO_SUBSTEPS = 4u, WI_ONE_POSITION_ITER = 8u, WI_ISLAND_SWEEPS_10 = 16u,
-                  WI_TOI_SWEEPS_12 = 32u, WI_NO_TOI_OTHER_UPDATES = 64u, WI_NO_FIND_CONTACTS = 128u };
+                  WI_TOI_SWEEPS_12 = 32u, WI_NO_TOI_OTHER_UPDATES = 64u, WI_NO_FIND_CONTACTS = 128u,
+                  WI_SUB_NO_POSITION = 256u, WI_SUB_NO_FIND = 512u, WI_SUB_NO_SYNC = 1024u, WI_SUB_NO_REEVAL = 2048u, WI_ONE_SUBSTEP = 4096u };
 #ifdef LL_WHATIF_BUILD  // iteration limits of the out-of-line loops travel as an extra argument in what-if builds only
 #define LL_WI_PARAM , int wi_limit
 #define LL_WI_ARG(w, bit, normal, limited) , (LL_WHATIF(w, bit) ? (limited) : (normal))
@@ -1066,7 +1067,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             edge_verts(w, ck_edge(key), ev[0], ev[1]);
             float beta;
             LL_STAMP(8);
-            int state = LL_WHATIF(w, WI_NO_TOI_EVAL) ? TOI_SEPARATED : time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
+            int state = (LL_WHATIF(w, WI_NO_TOI_EVAL) || (LL_WHATIF(w, WI_SUB_NO_REEVAL) && gA > 0.0f)) ? TOI_SEPARATED : time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
             LL_STAMP(9);
             float alpha;
             if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
@@ -1140,7 +1141,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         LL_STAMP(12);
         {
             Pos pd = pos[dyn];
-            toi_position(cs, pd);
+            if (!LL_WHATIF(w, WI_SUB_NO_POSITION)) toi_position(cs, pd);
             pos[dyn] = pd;
         }
         LL_STAMP(13);
@@ -1158,13 +1159,14 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         }
         LL_STAMP(11);
         int moved[1], nm = 0;
-        if (body_sync_fixtures(w, tab, dyn)) moved[nm++] = dyn;
+        if (!LL_WHATIF(w, WI_SUB_NO_SYNC) && body_sync_fixtures(w, tab, dyn)) moved[nm++] = dyn;
         for (int s = 0; s < kSlots; ++s) {
             const uint32_t key = ct_key(w.cs, s);
             if ((key & CK_EXISTS) && ck_body(key) == dyn) ct_set_key(w.cs, s, key & ~(CK_TOIFLAG | CK_ISLAND));
         }
-        find_new_contacts(w, moved, nm);
+        if (!LL_WHATIF(w, WI_SUB_NO_FIND)) find_new_contacts(w, moved, nm);
         LL_STAMP(18);
+        if (LL_WHATIF(w, WI_ONE_SUBSTEP)) { w.gA = gA; return true; }
     }
 }
 

@@ -51,6 +51,11 @@ int main(int argc, char** argv) {
         {WI_NO_SUBSTEPS, "SolveTOI: times of impact evaluated once, no sub-step taken"},
         {WI_TOI_SWEEPS_12, "sub-steps: at most 12 velocity sweeps"},
         {WI_NO_TOI_OTHER_UPDATES, "sub-steps: the body's other contacts are not updated"},
+        {WI_ONE_SUBSTEP, "sub-steps: at most one per env"},
+        {WI_SUB_NO_REEVAL, "sub-steps: no time_of_impact re-evaluation after the first sub-step (so at most one sub-step per body)"},
+        {WI_SUB_NO_POSITION, "sub-steps: no position iterations"},
+        {WI_SUB_NO_SYNC | WI_SUB_NO_FIND, "sub-steps: no fixture sync, no FindNewContacts"},
+        {WI_TOI_SWEEPS_12 | WI_SUB_NO_POSITION | WI_SUB_NO_SYNC | WI_SUB_NO_FIND | WI_NO_TOI_OTHER_UPDATES, "sub-steps: all of the sub-step cuts above except the count (what remains: evaluate, advance, update one contact, solver set-up, 12 sweeps)"},
         {WI_NO_COLLIDE_UPDATE | WI_ISLAND_SWEEPS_10 | WI_ONE_POSITION_ITER | WI_NO_FIND_CONTACTS | WI_NO_TOI_EVAL, "all of the above: load, integrate, store"},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
