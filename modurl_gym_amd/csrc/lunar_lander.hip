@@ -7,9 +7,17 @@
 // columns, ~1 KB per env of which ~0.45 KB are touched in free flight; see enum Col):
 //   3 bodies x {xf.p, sweep.c, angle, v, w, sleepTime}; 2 joints x {impulse.xy, motor, lower, upper};
 //   3 fat AABBs; terrain smooth_y[11]; prev_shaping; flag word; wind/torque indices; step/episode
-//   counters (Philox slots); 12 contact-cache slots x 16 words (loaded only when the env has contacts).
+//   counters (Philox slots); 12 contact-cache slots x 16 words (worked on in place, KEY/SEQ/TOI staged in LDS: ll_b2.h).
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
+//
+// One mgym_step (LunarLanderEnv::step, default = the overlapped order):
+//   ll_classify_kernel          contact list + class byte per env, from the flag words
+//   ll_contact_kernel<32|64>    contact path (Collide, island solve, SolveTOI) over that list      caller's stream
+//   ll_free_kernel              register-only step of everyone else, beside it                     helper stream
+//   ll_contact_kernel<32>       the few envs the free-flight kernel declined                       helper stream
+//   ll_reset_kernel<32>         fused auto-reset of the finished envs, after the join              caller's stream
+// MGYM_LL_OVERLAP=0 runs the same kernels one after the other (free-flight kernel first: it then builds the list).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,7 +42,7 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
 // Touching contacts one island may hold.  9 is the geometric bound of this scene: a body's polygon spans < 2 m (lander
 // 1.13 m, leg diagonal 0.55 m) while terrain edges are 2 m wide, so it can touch at most two adjacent terrain edges plus
-// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (LDS: 9 x 32 lanes x 124 B = 35.7 KB per block.)
+// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (LDS of a 32-lane block: 9 x 32 x 124 B = 35.7 KB + 4.6 KB of staged contact words.)
 #ifndef LL_SOLVER_CAP
 #define LL_SOLVER_CAP 9
 #endif
@@ -139,9 +147,10 @@ ll_classify_kernel(LLDev d) {
     }
 }
 
-// Stage 1 of mgym_step: every environment that is in free flight (no cached contact, all bodies awake) is
-// stepped here with the register-only fast path (ll_free.h); everything else — and every env the fast path
-// declines or that finished and must auto-reset — goes to the worklist for ll_general_kernel.
+// Every environment that is in free flight (no cached contact, all bodies awake) is stepped here with the
+// register-only fast path (ll_free.h).  Sequential order: everything else — and every env the fast path declines —
+// goes onto L_GENERAL for the contact kernel behind it.  Overlapped order (d.split): the contact class is being stepped
+// by the contact kernel beside this one; only the declined envs are listed (L_LATE).  Finished envs go onto L_RESET.
 template <int OCC>
 __global__ void __launch_bounds__(kLLBlock, OCC)
 ll_free_kernel(LLDev d, LLIo io) {
@@ -204,10 +213,11 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
     ll_write_obs(d, io, i, state);
 }
 
-// Stage 2 of mgym_step, on the compacted L_GENERAL list: wind / engines, b2World::Step up to and including the first
-// evaluation of the times of impact (collide, the 180-sweep island solve, position iterations, new contacts, one
-// b2TimeOfImpact per cached contact).  ~3/4 of the environments are done at that point (no impact within the step);
-// the rest go, with their unfinished SolveTOI state in the C_MID columns, onto L_TOI0 for ll_toi_kernel.
+// The contact path over a compacted list (`which` = L_GENERAL, or L_LATE for the second launch of the overlapped order):
+// wind / engines, then b2World::Step — Collide, the 180-sweep island solve, position iterations, new contacts, SolveTOI
+// with all its sub-steps (toi_budget < 0, the default).  With toi_budget >= 0 (MGYM_LL_TOI_ROUNDS, profiling only) SolveTOI
+// stops after that many sub-steps and the env goes, with its unfinished state in the C_MID columns, onto L_TOI0 for
+// ll_toi_kernel.
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
