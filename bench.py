@@ -190,6 +190,7 @@ def lunar_roofline(n, step_s):
         out["flop_per_step_active_lanes"] = rec["f32_flop_per_step_active_lanes"]
         out["flop_per_step_all_64_lanes"] = rec["f32_flop_per_step_lanes64"]
         out["frac_if_all_64_lanes_counted"] = rec["f32_flop_per_step_lanes64"] / step_s / 157.3e12
+        out["traffic"] = rec.get("hbm_bytes_per_step")   # FETCH_SIZE x2 + WRITE_SIZE summed over the step's launches (the bound is VALU: for reference)
         out["counter_source"] = rec.get("source")
     return out
 

@@ -42,7 +42,7 @@ def main():
                        write_bytes=d["write_bytes"], kernel_avg_ns=summ[name].get("avg_ns_steady"),
                        valu_insts_per_wave=d.get("valu_insts_per_wave"))
         else:
-            lanes64 = active = 0.0
+            lanes64 = active = hbm = 0.0
             per = {}
             steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_free_kernel" in k] + [1])  # one free-flight launch per step
             for k, v in summ.items():
@@ -54,10 +54,11 @@ def main():
                 act = f64 * d.get("mean_active_lanes_per_valu_inst", 64.0) / 64.0
                 lanes64 += f64
                 active += act
+                hbm += (d.get("fetch_bytes_x2", 0.0) + d.get("write_bytes", 0.0)) * per_step
                 per[k.split("(")[0].replace("void mgym::", "")] = {"avg_ns": v.get("avg_ns_steady"), "launches_per_step": per_step, "f32_flop_lanes64": f64, "f32_flop_active_lanes": act,
                                                                    "mean_active_lanes": d.get("mean_active_lanes_per_valu_inst"),
                                                                    "valu_busy_share_of_wave_cycles": d.get("valu_active_share_of_wave_cycles")}
-            rec.update(f32_flop_per_step_lanes64=lanes64, f32_flop_per_step_active_lanes=active, kernels=per,
+            rec.update(f32_flop_per_step_lanes64=lanes64, f32_flop_per_step_active_lanes=active, hbm_bytes_per_step=hbm, kernels=per,
                        note="per step (launches_per_step x the per-launch average; the kernels of one step overlap in time); flop = 64 x (2 x SQ_INSTS_VALU_FMA_F32 + MUL_F32 + ADD_F32), weighted by "
                             "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (mean active lanes per VALU instruction) for the active-lane figure")
         out[key] = rec
