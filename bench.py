@@ -153,11 +153,8 @@ def host_cores():
 
 
 def kernel_source_sha16(files):
-    import hashlib
-    h = hashlib.sha256()
-    for f in files:
-        h.update(open(os.path.join(ROOT, "modurl_gym_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from modurl_gym_amd._srchash import kernel_source_sha16 as f  # comments and blank lines do not count
+    return f(files)
 
 
 def pmc_record(key):

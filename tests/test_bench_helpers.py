@@ -30,6 +30,14 @@ def test_counter_records_are_dropped_when_the_kernel_sources_changed(tmp_path, m
     assert bench.pmc_record("no-such-key") is None
 
 
+def test_source_hash_ignores_comments_but_not_code():
+    from modurl_gym_amd._srchash import code_only
+    a = "int f(int x) {  // adds one\n    /* really\n       it does */\n    return x + 1;\n}\n\n"
+    b = "int f(int x) {\n    return x + 1;   // a different remark\n}\n"
+    c = "int f(int x) {\n    return x + 2;\n}\n"
+    assert code_only(a) == code_only(b) != code_only(c)
+
+
 def test_host_cores_follows_affinity_and_override(monkeypatch):
     n = bench.host_cores()
     assert 1 <= n <= 64 and n <= len(os.sched_getaffinity(0))

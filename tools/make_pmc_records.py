@@ -17,10 +17,9 @@ SRC = {"cartpole": ["cartpole.hip", "cartpole_step.h", "cartpole_math.h", "mgym_
 
 
 def sha16(files):
-    h = hashlib.sha256()
-    for f in files:
-        h.update(open(os.path.join(CSRC, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from modurl_gym_amd._srchash import kernel_source_sha16
+    return kernel_source_sha16(files)
 
 
 def main():
