@@ -381,6 +381,7 @@ int mgym_graph_end(mgym_env* env, void** graph_exec_out) {
     ENV_OR_FAIL(env);
     if (!graph_exec_out) return bad_arg("mgym_graph_end: NULL");
     hipGraph_t g = nullptr;
+    { int st = e->join_helpers(); if (st != MGYM_OK) return st; }
     MGYM_HIP(hipStreamEndCapture(e->stream, &g));
     hipGraphExec_t ge = nullptr;
     hipError_t err = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);

@@ -73,6 +73,8 @@ struct Env {
     // Testable::reset_deterministic of the reference's test modules (cartpole.rs:437-442, mountain_car.rs:403-408,
     // lunar_lander.rs:1249-1442)
     virtual int reset_deterministic(float* obs_out) = 0;
+    // helper streams forked from `stream` must have rejoined it before a stream capture ends (mgym_graph_end)
+    virtual int join_helpers() { return MGYM_OK; }
     virtual int set_dispersion(const float*) { set_last_error("dispersion override: LunarLander only"); return MGYM_ERR_BAD_ARG; }
 };
 

@@ -58,6 +58,8 @@ struct LLDev {
     VConstraint* vc_far;  // workspace for the velocity constraints that do not fit a block's LDS: [kSolverCap - near][contact-kernel lanes]
     int auto_reset;
     int bucket;  // worklist bucketing by F_TOUCHING
+    const uint32_t* episode_src;  // staged resets: this LLDev addresses the SHADOW columns; the episode counter comes from the live ones
+    int prep;            // staged resets: ll_reset_kernel lists the envs it has reset (L_PREP), their next reset is then prepared
     uint8_t* env_class;  // overlapped launch order: class byte per env for this step (ll_classify_kernel)
     int split;   // 0: sequential launch order; 1: overlapped (contact list built by ll_classify_kernel; the free-flight kernel lists only what it declines)
 #ifdef LL_WHATIF_BUILD

@@ -57,9 +57,12 @@ constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kW
 //                worklist kernel hold environments of one kind (180 joint-only sweeps vs. sweeps with contact constraints).
 //   L_RESET      finished envs to reset (register-only fast path); L_RESET_SLOW: resets the fast path declined
 //   L_LATE       overlapped launch order only: envs the free-flight kernel had to decline (a contact would be created)
+//   L_RESET_DIRECT  staged resets: finished envs whose prepared episode does not fit (state imported, reset by the caller): reset the slow way
+//   L_PREP       staged resets: envs that have just been reset and whose NEXT reset is to be prepared (+ L_PREP_SLOW: declined by the fast path)
 //   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
 constexpr int kToiRounds = 4;
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_TOI0 = 5, L_COUNT = L_TOI0 + kToiRounds };
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, L_COUNT = L_TOI0 + kToiRounds,
+       L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed at the start of every call)
 
 struct LLIo {
     const uint32_t* act;
@@ -429,7 +432,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
 // an inline reset made every block pay a second full world step.
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
-ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count) {
+ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int slow_list) {
     __shared__ PolyTab tab;
     LL_HOT_DECL(BLK);
     stage_tab(tab, LLK(d));
@@ -440,6 +443,7 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
         bool slow = false;
         if (q < total) {
             if (list) i = list[q];
+            if (d.episode_src) ST(C_EPISODE) = d.episode_src[(uint64_t)C_EPISODE * d.n_pad + i];  // preparing in the shadow columns: the episode to draw is the live one
             V2 force; float torque;
             {
                 World w; EnvRegs e;
@@ -461,7 +465,53 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
                 slow = true;
             }
         }
-        ll_push(d, L_RESET_SLOW, slow, (uint32_t)i | kWorkReset);
+        ll_push(d, slow_list, slow, (uint32_t)i | kWorkReset);
+        if (d.prep && list) ll_push(d, L_PREP, q < total && !slow, (uint32_t)i);
+    }
+}
+
+// Staged resets.  The state an env has after reset() — scene, implicit step(0), observation — is a pure function of
+// (seed, env id, episode counter), so it does not have to be computed when the episode ends, on the critical path of
+// that step (reset kernel: 0.11 ms behind the contact kernel): it is PREPARED in advance, in shadow columns, by the same
+// reset kernels on a third stream while later steps run, and the auto-reset of a finished env is a copy.
+// The prepared state carries its episode counter: it fits iff shadow episode == live episode + 1; whatever changed the
+// live counter in between (mgym_reset, mgym_set_state) just sends the env down the direct path (L_RESET_DIRECT) once.
+// (1) which finished envs have a fitting prepared state: those go onto L_PREP (their reset is the copy below, and their
+//     NEXT reset is prepared afterwards), the others onto L_RESET_DIRECT.  One thread per list entry, one atomic per block and list.
+__global__ void __launch_bounds__(256)
+ll_apply_select_kernel(LLDev d, const uint32_t* __restrict__ shadow) {
+    __shared__ uint32_t s_cnt[5];
+    const uint32_t* list = d.work_list + (uint64_t)L_RESET * d.n_pad;
+    const uint64_t total = d.work_count[L_RESET];
+    for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {  // block-uniform
+        const uint64_t q = q0 + threadIdx.x;
+        uint64_t i = 0;
+        bool fits = false, direct = false;
+        if (q < total) {
+            i = list[q];
+            fits = shadow[(uint64_t)C_EPISODE * d.n_pad + i] == ST(C_EPISODE) + 1u;
+            direct = !fits;
+        }
+        ll_push_block(d, L_PREP, fits, (uint32_t)i, s_cnt);
+        ll_push_block(d, L_RESET_DIRECT, direct, (uint32_t)i, s_cnt);
+    }
+}
+// (2) the copy: one block per env of L_PREP, one thread per word (the columns of one env lie n_pad words apart)
+__global__ void __launch_bounds__(128)
+ll_apply_copy_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __restrict__ shadow_obs, LLIo io) {
+    const uint32_t* list = d.work_list + (uint64_t)L_PREP * d.n_pad;
+    const uint64_t total = d.work_count[L_PREP];
+    const int t = threadIdx.x;
+    for (uint64_t q = blockIdx.x; q < total; q += gridDim.x) {
+        const uint64_t i = list[q];
+        if (t < C_CONTACT) ST(t) = shadow[(uint64_t)t * d.n_pad + i];
+        else if (t < C_CONTACT + kSlots) ST(C_CONTACT + 16 * (t - C_CONTACT)) = 0u;  // a fresh world has no contacts
+        else if (t < C_CONTACT + kSlots + 8) {
+            const int k = t - C_CONTACT - kSlots;
+            const float o = shadow_obs[(uint64_t)k * d.n_pad + i];
+            d.obs[(uint64_t)k * d.n_pad + i] = o;
+            if (io.obs_out) io.obs_out[(uint64_t)k * d.n + i] = o;
+        }
     }
 }
 
@@ -527,6 +577,12 @@ struct LunarLanderEnv final : Env {
     void* vc_far_base = nullptr;
     hipStream_t aux = nullptr;          // helper stream of the overlapped launch order
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* shadow_base = nullptr;        // staged resets: shadow state columns [C_COUNT][n_pad] and observation [8][n_pad]
+    void* shadow_obs = nullptr;
+    hipStream_t aux2 = nullptr;         // ... prepared on this stream
+    hipEvent_t ev_prep = nullptr, ev_prepared = nullptr;
+    bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
+    int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
     uint8_t* env_class = nullptr;       // [n] class of each env for this step (ll_classify_kernel): 0 free flight, 1 contact path
     int overlap = getenv("MGYM_LL_OVERLAP") ? atoi(getenv("MGYM_LL_OVERLAP")) : -1;  // 1 (default): contact kernel beside the free-flight kernel (see step()); 0: one after the other
     LLDev dev{};
@@ -552,6 +608,11 @@ struct LunarLanderEnv final : Env {
         if (vc_far_base) (void)hipFree(vc_far_base);
         if (aux) (void)hipStreamDestroy(aux);
         if (env_class) (void)hipFree(env_class);
+        if (aux2) { (void)hipStreamSynchronize(aux2); (void)hipStreamDestroy(aux2); }
+        if (shadow_base) (void)hipFree(shadow_base);
+        if (shadow_obs) (void)hipFree(shadow_obs);
+        if (ev_prep) (void)hipEventDestroy(ev_prep);
+        if (ev_prepared) (void)hipEventDestroy(ev_prepared);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
     }
@@ -577,8 +638,8 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemsetAsync(obs_base, 0, (size_t)8 * n_pad * sizeof(float), stream));
         dev.st = static_cast<uint32_t*>(base);
         dev.obs = static_cast<float*>(obs_base);
-        MGYM_HIP(hipMalloc(&work_base, (size_t)(L_COUNT * n_pad + 64) * sizeof(uint32_t)));
-        MGYM_HIP(hipMemsetAsync(work_base, 0, (size_t)(L_COUNT * n_pad + 64) * sizeof(uint32_t), stream));
+        MGYM_HIP(hipMalloc(&work_base, (size_t)(L_LISTS * n_pad + 64) * sizeof(uint32_t)));
+        MGYM_HIP(hipMemsetAsync(work_base, 0, (size_t)(L_LISTS * n_pad + 64) * sizeof(uint32_t), stream));
         dev.work_count = static_cast<uint32_t*>(work_base);
         dev.work_list = static_cast<uint32_t*>(work_base) + 64;
         dev.disp = nullptr;
@@ -603,6 +664,45 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         MGYM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         dev.split = 0;
+        dev.prep = 0; dev.episode_src = nullptr;
+        // (pays while the step is bound by the contact kernel's chain: 131 072 envs 1.43 -> 1.36 ms per step, 262 144 1.50 -> 1.46;
+        // a population that fills every wave slot gains nothing from moving the reset work and loses to the extra launches:
+        // 1 Mi envs 3.53 -> 3.84; MGYM_LL_STAGED_RESET=2 forces it on)
+        staged = (staged == 2 || (staged == 1 && n < 327680)) && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
+        if (staged) {
+            MGYM_HIP(hipMalloc(&shadow_base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
+            MGYM_HIP(hipMemsetAsync(shadow_base, 0, (size_t)C_COUNT * n_pad * sizeof(uint32_t), stream));
+            MGYM_HIP(hipMalloc(&shadow_obs, (size_t)8 * n_pad * sizeof(float)));
+            MGYM_HIP(hipMemsetAsync(shadow_obs, 0, (size_t)8 * n_pad * sizeof(float), stream));
+            int lo = 0, hi = 0;
+            MGYM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MGYM_HIP(hipStreamCreateWithPriority(&aux2, hipStreamNonBlocking, lo));
+            MGYM_HIP(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
+            MGYM_HIP(hipEventCreateWithFlags(&ev_prepared, hipEventDisableTiming));
+        }
+        return MGYM_OK;
+    }
+    bool staging() const { return staged && dev.disp == nullptr; }  // (a dispersion override would be baked into prepared states)
+    // `stream` waits for the preparation work put on aux2 so far: before anything appends to L_PREP or reads the shadow columns
+    int join_helpers() override {
+        if (prep_pending) { MGYM_HIP(hipStreamWaitEvent(stream, ev_prepared, 0)); prep_pending = false; }
+        return MGYM_OK;
+    }
+    // prepare the next reset of the envs on L_PREP (or of every env), after what `stream` holds so far
+    int launch_prepare(bool all) {
+        LLDev sh = dev;
+        sh.st = static_cast<uint32_t*>(shadow_base); sh.obs = static_cast<float*>(shadow_obs);
+        sh.episode_src = dev.st; sh.prep = 0; sh.split = 0;
+        const LLIo none{nullptr, nullptr, nullptr, nullptr, nullptr};
+        MGYM_HIP(hipEventRecord(ev_prep, stream));
+        MGYM_HIP(hipStreamWaitEvent(aux2, ev_prep, 0));
+        if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, aux2, sh, none, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)L_PREP_SLOW);
+        else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, aux2, sh, none, list_ptr(L_PREP), (const uint32_t*)dev.work_count + L_PREP, (int)L_PREP_SLOW);
+        // (an env the fast path declines — it never does for a fresh scene — keeps a shadow episode that does not fit and
+        // takes the direct path at its next reset; L_PREP_SLOW is only a sink)
+        MGYM_HIP(hipMemsetAsync(dev.work_count + L_PREP, 0, 2 * sizeof(uint32_t), aux2));
+        MGYM_HIP(hipEventRecord(ev_prepared, aux2));
+        prep_pending = true;
         return MGYM_OK;
     }
 
@@ -619,11 +719,13 @@ struct LunarLanderEnv final : Env {
 
     const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
     // resets of the envs on the L_RESET list (or of every env): fast path, then the (normally empty) declined list
-    void launch_resets(const LLIo& io, bool all) {
-        if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-        else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, dev, io, list_ptr(L_RESET), (const uint32_t*)dev.work_count + L_RESET);
+    void launch_resets(const LLIo& io, bool all, int from_list = L_RESET) {
+        LLDev d = dev;
+        d.prep = staging() ? 1 : 0;   // the envs reset here get their next reset prepared
+        if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, stream, d, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)L_RESET_SLOW);
+        else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, d, io, list_ptr(from_list), (const uint32_t*)dev.work_count + from_list, (int)L_RESET_SLOW);
         // declined resets are rare to non-existent: a small grid (grid-stride inside) keeps the usual empty launch cheap
-        hipLaunchKernelGGL(ll_general_kernel<64>, dim3(work_grid().x < 64 ? work_grid().x : 64), dim3(64), 0, stream, dev, io, list_ptr(L_RESET_SLOW), (const uint32_t*)dev.work_count + L_RESET_SLOW, 0);
+        hipLaunchKernelGGL(ll_general_kernel<64>, dim3(work_grid().x < 64 ? work_grid().x : 64), dim3(64), 0, stream, d, io, list_ptr(L_RESET_SLOW), (const uint32_t*)dev.work_count + L_RESET_SLOW, 0);
     }
     int reset(const uint8_t* m0, const uint8_t* m1, bool all, float* obs_out) override {
         if (n == 0) return MGYM_OK;
@@ -632,8 +734,10 @@ struct LunarLanderEnv final : Env {
         if (general_only && all) {  // debugging aid: reset + implicit step on the general path
             hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
         } else {
+            if (staging()) { int st = join_helpers(); if (st != MGYM_OK) return st; }
             if (!all) hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
             launch_resets(io, all);
+            if (staging()) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
@@ -705,7 +809,18 @@ struct LunarLanderEnv final : Env {
         }
         if (dev.auto_reset) {  // finished envs were compacted onto L_RESET by both kernels; outputs of the step stay as written
             LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};
-            launch_resets(rio, false);
+            if (staging()) {
+                int st = join_helpers();
+                if (st != MGYM_OK) return st;
+                hipLaunchKernelGGL(ll_apply_select_kernel, dim3(work_grid().x < 64 ? work_grid().x : 64), dim3(256), 0, stream, dev, (const uint32_t*)shadow_base);
+                hipLaunchKernelGGL(ll_apply_copy_kernel, dim3(work_grid().x < 2048 ? work_grid().x : 2048), dim3(128), 0, stream, dev,
+                                   (const uint32_t*)shadow_base, (const float*)shadow_obs, rio);
+                launch_resets(rio, false, L_RESET_DIRECT);   // normally empty
+                st = launch_prepare(false);
+                if (st != MGYM_OK) return st;
+            } else {
+                launch_resets(rio, false);
+            }
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
@@ -727,6 +842,11 @@ struct LunarLanderEnv final : Env {
         return MGYM_OK;
     }
     int set_dispersion(const float* disp) override {
+        if (staged) {  // states prepared under the other dispersion source no longer fit: episode 0 never equals a live counter + 1
+            int st = join_helpers();
+            if (st != MGYM_OK) return st;
+            MGYM_HIP(hipMemsetAsync(static_cast<uint32_t*>(shadow_base) + (size_t)C_EPISODE * n_pad, 0, n_pad * sizeof(uint32_t), stream));
+        }
         dev.disp = disp;
         return MGYM_OK;
     }

@@ -14,7 +14,7 @@ for f in glob.glob("/tmp/llov/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 ll = [r for r in rows if "ll_" in r[2] or "fillBuffer" in r[2]]
 # the last two steps
-tail = ll[-16:]
+tail = ll[-26:]
 t0 = tail[0][0]
 for r in tail:
     print("%9.1f us -> %9.1f us  (%8.1f us)  queue %s  %s" % ((r[0] - t0) / 1e3, (r[1] - t0) / 1e3, (r[1] - r[0]) / 1e3, r[3], r[2]))
