@@ -26,6 +26,11 @@ import os
 import sys
 import time
 
+# The HIP runtime gives a process 4 hardware queues per device by default and lets further streams share them; streams that
+# share a queue run one after the other.  This bench keeps up to three family streams plus LunarLander's helper stream (and
+# torch's own) alive at once, and the overlaps it measures must be real ones: ask for 8 (a runtime knob of ROCclr, read at init).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -43,7 +48,9 @@ def parse():
     ap.add_argument("--workload", default="cartpole",
                     choices=["cartpole", "mountain_car", "mountain_car_cont", "lunar_lander", "mixed"])
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: BASELINE size)")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="auto: hipGraph replay for the launch-bound families (CartPole, MountainCar: ~10 us steps); eager for LunarLander, "
+                         "whose ~1.5 ms step hides the launch latency and whose prepared resets run on a side stream only outside graphs")
     ap.add_argument("--reset", default="fused", choices=["fused", "separate"],
                     help="fused: auto-reset inside the step kernel; separate: step + mgym_reset_done launch")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -55,6 +62,14 @@ def parse():
     return ap.parse_args()
 
 
+def launch_mode(requested, family):
+    """`--launch auto`: hipGraph replay for the launch-bound families, eager launches for LunarLander (a ~1.5 ms step hides the
+    launch latency; its prepared resets use a side stream only outside graphs)."""
+    if requested != "auto":
+        return requested
+    return "eager" if family == "lunar_lander" else "graph"
+
+
 class Stepper:
     """One env family on this rank: device buffers, an action ring and a (graph-captured) step."""
 
@@ -62,7 +77,7 @@ class Stepper:
         kinds = {"cartpole": (mg.CARTPOLE, 2), "mountain_car": (mg.MOUNTAINCAR, 3),
                  "mountain_car_cont": (mg.MOUNTAINCAR_CONT, 0), "lunar_lander": (mg.LUNARLANDER, 4)}
         kind, nact = kinds[kind_name]
-        self.name, self.n, self.reset_mode, self.launch = kind_name, n, reset_mode, launch
+        self.name, self.n, self.reset_mode, self.launch = kind_name, n, reset_mode, launch_mode(launch, kind_name)
         extra = dict(enable_wind=True) if kind_name == "lunar_lander" else {}
         self.env = mg.VecEnv(kind, n, device=device, seed=seed, env_id_base=base, auto_reset=(reset_mode == "fused"),
                              stream=stream.cuda_stream, **extra)
@@ -292,9 +307,9 @@ def main():
             s.run(steps)
 
     # short timed regions (the driver runs --steps 20): ONE graph of exactly K launches with the event records inside
-    one_graph = args.launch == "graph" and args.steps <= 256
-    if args.launch == "graph":
-        for s in steppers:
+    one_graph = args.steps <= 256
+    for s in steppers:
+        if s.launch == "graph":
             s.build_graph(args.warmup)   # capture + instantiate before anything is timed, whatever the warm-up length
             if one_graph:
                 s.build_timed_graph(args.steps)
@@ -308,11 +323,11 @@ def main():
     torch.cuda.synchronize()
     lead.env.timer_start()            # hipEvent on the launch stream
     t0 = time.perf_counter()
-    if one_graph:
-        for s in steppers:
+    for s in steppers:
+        if s.launch == "graph" and one_graph:
             s.run_timed(args.steps)   # EXACTLY K steps: one hipGraphLaunch
-    else:
-        run(args.steps)               # EXACTLY K steps
+        else:
+            s.run(args.steps)         # EXACTLY K steps (graph replays, or eager launches)
     ev_ms = lead.env.timer_stop()     # second hipEvent + hipEventSynchronize
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -335,7 +350,8 @@ def main():
         "config": {"workload": {"cartpole": "CartPole-v1, 1048576 envs per GPU, f32 SoA (BASELINE configs[1])",
                                 "mixed": "Mixed CartPole+MountainCar+LunarLander, 1048576 envs per GPU (BASELINE configs[4] per-GPU load)"}
                    .get(args.workload, args.workload),
-                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": (f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if args.launch == "graph" else "eager",
+                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": ", ".join(sorted({((f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if s_.launch == "graph" else "eager")
+                                                + (f" [{s_.name}]" if len(steppers) > 1 else "") for s_ in steppers})),
                    "reset": "fused auto-reset in the step kernel" if args.reset == "fused" else "separate mgym_reset_done launch per step",
                    "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING,
                    "scaling": ("weak: fixed envs per GPU" if args.scaling == "weak" else f"strong: {total_envs} envs fixed for the node, contiguous index blocks per rank")},
@@ -352,7 +368,7 @@ def main():
                               "avg_launch_us": dur * 1e6,
                               "note": "algorithmic bytes/env-step x envs per launch / HIP-event time per launch; at 1Mi envs the working set "
                                       "(~50 MB) is Infinity-Cache resident, see DESIGN.md for the >256 MiB run"}
-        if args.steps < 256 and args.launch == "graph":
+        if args.steps < 256 and lead.launch == "graph":
             # A short timed region (the driver runs --steps 20) starts on an idle stream, so its event interval carries
             # the host's graph-launch latency (10-20 us) and the clock ramp.  Report, beside it and AFTER the timed
             # region, the same kernel's steady per-launch time: HIP events around 30 replays of the 16-step graph.

@@ -373,6 +373,7 @@ int mgym_timer_stop(mgym_env* env, float* elapsed_ms) {
 
 int mgym_graph_begin(mgym_env* env) {
     ENV_OR_FAIL(env);
+    { int st = e->join_helpers(); if (st != MGYM_OK) return st; }  // helper-stream work issued so far is waited for OUTSIDE the capture
     MGYM_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     return MGYM_OK;
 }

@@ -579,7 +579,7 @@ struct LunarLanderEnv final : Env {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* shadow_base = nullptr;        // staged resets: shadow state columns [C_COUNT][n_pad] and observation [8][n_pad]
     void* shadow_obs = nullptr;
-    hipStream_t aux2 = nullptr;         // ... prepared on this stream
+    hipStream_t aux2 = nullptr;         // ... prepared on this stream (its own: behind the free-flight kernel on `aux` it costs 0.1 ms per step)
     hipEvent_t ev_prep = nullptr, ev_prepared = nullptr;
     bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
     int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
@@ -683,6 +683,16 @@ struct LunarLanderEnv final : Env {
         return MGYM_OK;
     }
     bool staging() const { return staged && dev.disp == nullptr; }  // (a dispersion override would be baked into prepared states)
+    // ... and not while the caller's stream is being captured: replayed as a hipGraph the third branch costs more than it
+    // saves (the graph executor keeps neither the stream priorities nor, reliably, the overlap: up to 2.00 ms per step against
+    // 1.49 at 262 144 envs, profiles/r02_lunarlander/launch_modes.txt), so captured steps reset directly; their envs' prepared
+    // states are then simply stale (episode check) the next time a step runs eagerly.
+    bool staging_now() const {
+        if (!staging()) return false;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) return false;
+        return cs == hipStreamCaptureStatusNone;
+    }
     // `stream` waits for the preparation work put on aux2 so far: before anything appends to L_PREP or reads the shadow columns
     int join_helpers() override {
         if (prep_pending) { MGYM_HIP(hipStreamWaitEvent(stream, ev_prepared, 0)); prep_pending = false; }
@@ -719,9 +729,9 @@ struct LunarLanderEnv final : Env {
 
     const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
     // resets of the envs on the L_RESET list (or of every env): fast path, then the (normally empty) declined list
-    void launch_resets(const LLIo& io, bool all, int from_list = L_RESET) {
+    void launch_resets(const LLIo& io, bool all, int from_list = L_RESET, bool prep = false) {
         LLDev d = dev;
-        d.prep = staging() ? 1 : 0;   // the envs reset here get their next reset prepared
+        d.prep = prep ? 1 : 0;   // the envs reset here are listed so that their next reset gets prepared
         if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, stream, d, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)L_RESET_SLOW);
         else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, stream, d, io, list_ptr(from_list), (const uint32_t*)dev.work_count + from_list, (int)L_RESET_SLOW);
         // declined resets are rare to non-existent: a small grid (grid-stride inside) keeps the usual empty launch cheap
@@ -734,10 +744,11 @@ struct LunarLanderEnv final : Env {
         if (general_only && all) {  // debugging aid: reset + implicit step on the general path
             hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
         } else {
-            if (staging()) { int st = join_helpers(); if (st != MGYM_OK) return st; }
+            const bool stage = staging_now();
+            if (stage) { int st = join_helpers(); if (st != MGYM_OK) return st; }
             if (!all) hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
-            launch_resets(io, all);
-            if (staging()) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
+            launch_resets(io, all, L_RESET, stage);
+            if (stage) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
@@ -809,13 +820,13 @@ struct LunarLanderEnv final : Env {
         }
         if (dev.auto_reset) {  // finished envs were compacted onto L_RESET by both kernels; outputs of the step stay as written
             LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};
-            if (staging()) {
+            if (staging_now()) {
                 int st = join_helpers();
                 if (st != MGYM_OK) return st;
                 hipLaunchKernelGGL(ll_apply_select_kernel, dim3(work_grid().x < 64 ? work_grid().x : 64), dim3(256), 0, stream, dev, (const uint32_t*)shadow_base);
                 hipLaunchKernelGGL(ll_apply_copy_kernel, dim3(work_grid().x < 2048 ? work_grid().x : 2048), dim3(128), 0, stream, dev,
                                    (const uint32_t*)shadow_base, (const float*)shadow_obs, rio);
-                launch_resets(rio, false, L_RESET_DIRECT);   // normally empty
+                launch_resets(rio, false, L_RESET_DIRECT, true);   // normally empty
                 st = launch_prepare(false);
                 if (st != MGYM_OK) return st;
             } else {
