@@ -597,6 +597,7 @@ struct LunarLanderEnv final : Env {
     // heavy lanes (bucketing) lengthens that wave, and follow-up launches serialise the same chain behind launch
     // boundaries and a state round trip.  The alternatives stay selectable for profiling:
     int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : 0;       // 1: touching / non-touching envs at opposite ends of the worklist
+    int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 
@@ -787,7 +788,8 @@ struct LunarLanderEnv final : Env {
         }
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
         const unsigned gb = (unsigned)(((uint64_t)work_grid().x * 64 + gen_block - 1) / gen_block);
-        if (overlap && toi_rounds == 0) {
+        const int first_budget = toi_rounds > 0 ? toi_first : -1;  // sub-steps the contact kernel takes itself before handing an env to ll_toi_kernel
+        if (overlap) {
             // Overlapped order (see ll_classify_kernel): the contact kernel starts at once on the caller's stream; beside it,
             // on the helper stream, the free-flight kernel over everyone else, followed by a short contact launch for the
             // envs it declined (a contact was created at the end of their step).  Stream-ordered for the caller and
@@ -795,17 +797,17 @@ struct LunarLanderEnv final : Env {
             LLDev sd = dev; sd.split = 1;
             hipLaunchKernelGGL(ll_classify_kernel, dim3((unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256)), dim3(1024), 0, stream, sd);
             MGYM_HIP(hipEventRecord(ev_fork, stream));
-            launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
+            launch_contact(stream, gen_block, gb, sd, io, first_budget, L_GENERAL);
             MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             launch_free(aux, sd, io);
-            launch_contact(aux, 32, work_grid().x < 256 ? work_grid().x : 256, sd, io, -1, L_LATE);
+            launch_contact(aux, 32, work_grid().x < 256 ? work_grid().x : 256, sd, io, first_budget, L_LATE);
             MGYM_HIP(hipEventRecord(ev_join, aux));
             MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
             launch_free(stream, dev, io);
             // contact path on the compacted list, then the time-of-impact rounds over ever shorter lists (fixed grids,
             // grid-stride inside: the list lengths only exist on the device)
-            launch_contact(stream, gen_block, gb, dev, io, toi_rounds > 0 ? 0 : -1, L_GENERAL);
+            launch_contact(stream, gen_block, gb, dev, io, first_budget, L_GENERAL);
         }
         for (int r = 0; r < toi_rounds; ++r) {
             unsigned g = (work_grid().x * (64 / toi_block)) >> (r + 1);
