@@ -46,6 +46,41 @@ def test_policy_loop_on_torch_stream_matches_oracle():
     assert finished > 0  # the fused auto-reset was exercised
 
 
+def test_lunar_lander_on_alternating_torch_streams_matches_a_plain_handle():
+    """LunarLander forks helper streams from whatever stream the caller steps on and prepares resets beside later steps:
+    stepping alternately on two torch streams (ordered by the caller with wait_stream, no host sync) must give the words a
+    plain handle on its own stream gives."""
+    n, T = 8192, 150
+    env = mg.TorchVecEnv(mg.LUNARLANDER, n, seed=13, enable_wind=True, auto_reset=True)
+    ref = mg.VecEnv(mg.LUNARLANDER, n, seed=13, enable_wind=True, auto_reset=True)
+    obs0 = env.reset()
+    assert np.array_equal(obs0.cpu().numpy(), ref.reset())
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    acts = torch.randint(0, 4, (T, n), generator=gen, dtype=torch.int32).to(env.device)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(env.device), torch.cuda.Stream(env.device)]
+    outs = []
+    prev = torch.cuda.current_stream(env.device)
+    for t in range(T):
+        s = streams[t % 2]
+        s.wait_stream(prev)          # the caller's ordering between its own streams
+        with torch.cuda.stream(s):
+            obs, rew, done, trunc = env.step(acts[t])
+            outs.append((obs.clone(), rew.clone(), done.clone()))
+        prev = s
+    torch.cuda.synchronize()
+    env.check()
+    finished = 0
+    for t in range(T):
+        e_obs, e_rew, e_done, _ = ref.step(acts[t].cpu().numpy().astype(np.uint32))
+        g_obs, g_rew, g_done = (x.cpu().numpy() for x in outs[t])
+        assert np.array_equal(g_done, e_done.astype(bool)), t
+        assert np.array_equal(g_rew.view(np.uint32), e_rew.view(np.uint32)), t
+        assert np.array_equal(g_obs.view(np.uint32), e_obs.view(np.uint32)), t
+        finished += int(e_done.sum())
+    assert finished > n // 2   # auto-resets (prepared ahead on the helper stream) happened throughout
+
+
 def test_aos_layout_and_zero_copy_view():
     n = 3000
     env = mg.TorchVecEnv(mg.LUNARLANDER, n, seed=3, auto_reset=False, obs_layout="aos", enable_wind=True)
