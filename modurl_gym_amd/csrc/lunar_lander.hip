@@ -42,12 +42,12 @@ __device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
 constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
 // Touching contacts one island may hold.  9 is the geometric bound of this scene: a body's polygon spans < 2 m (lander
 // 1.13 m, leg diagonal 0.55 m) while terrain edges are 2 m wide, so it can touch at most two adjacent terrain edges plus
-// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (LDS of a 32-lane block: 9 x 32 x 124 B = 35.7 KB + 4.6 KB of staged contact words.)
+// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (In LDS the contact kernel keeps the first 4 per lane, see kVcNearLds.)
 #ifndef LL_SOLVER_CAP
 #define LL_SOLVER_CAP 9
 #endif
 constexpr int kSolverCap = LL_SOLVER_CAP;
-constexpr int kVcNear64 = 4;  // of those, kept in LDS by a 64-lane block of the contact kernel (4 blocks per CU); the rest in LLDev::vc_far
+constexpr int kVcNearLds = 4;  // of those, kept in LDS by the contact kernel (4 blocks per CU in either block size); the rest in LLDev::vc_far
 // the staged KEY / SEQ / TOI words of the contact cache (ll_b2.h CtHot): one LDS column per lane of the block
 #define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ), 1u}
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
@@ -225,7 +225,13 @@ template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
-    constexpr int kVcNear = BLK > 32 ? kVcNear64 : kSolverCap;
+    // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes: 536 B per lane,
+    // indexed by body / edge at run time) in LDS instead of scratch: ~100 cycles per dependent access instead of >= 500, and
+    // 450 B less scratch per lane (1.45 -> 1.40 ms per step at 262 144 envs).  LDS of a 32-lane block: 4 x 32 x 124 B
+    // constraints + 4.6 KB staged contact words + 16.8 KB World + table = 36.9 KB (four blocks per CU).
+    constexpr bool kWorldLds = BLK <= 32;
+    constexpr int kVcNear = kVcNearLds;
+    __shared__ World s_world[kWorldLds ? BLK : 1];
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kVcNear * BLK];
     __shared__ uint32_t s_hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
@@ -258,7 +264,9 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
             } else {
                 i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
             }
-            World w; EnvRegs e;
+            World w_local;
+            World& w = kWorldLds ? s_world[kWorldLds ? threadIdx.x : 0] : w_local;
+            EnvRegs e;
             ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
@@ -624,7 +632,7 @@ struct LunarLanderEnv final : Env {
         //     131 072 envs  1.58 -> 1.43 / 1.67 -> 1.54        524 288 envs  2.90 -> 2.71 / 2.38 -> 1.87
         //     262 144 envs  1.82 -> 1.52 / 1.94 -> 1.71      1 048 576 envs  4.85 -> 4.91 / 3.99 -> 3.66
         //     393 216 envs  2.55 -> 2.15 / 2.20 -> 1.79      2 097 152 envs  8.64 -> 8.71 / 7.02 -> 6.78
-        // 32-lane blocks (all 9 velocity constraints per lane in LDS) give the shortest waves: best while the whole
+        // 32-lane blocks (which also afford the World record in LDS) give the shortest waves: best while the whole
         // worklist is co-resident.  Beyond that the kernel is bound by wave slots — one 512-register wave per SIMD, four
         // blocks per CU by LDS — and 64-lane blocks (4 constraints per lane in LDS, the rest in LLDev::vc_far) carry twice
         // the environments per slot.  The overlapped order (contact kernel beside the free-flight kernel, see step()) pays
@@ -652,7 +660,7 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
         dev.kd = static_cast<const LLConst*>(kdev);
         // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
-        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNear64) * work_grid().x * 64 * sizeof(VConstraint)));
+        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds) * work_grid().x * 64 * sizeof(VConstraint)));
         dev.vc_far = static_cast<VConstraint*>(vc_far_base);
         {   // the helper stream carries the work that is NOT on the critical path: lowest priority (1 Mi envs: 3.65 -> 3.52 ms per step)
             int lo = 0, hi = 0;
