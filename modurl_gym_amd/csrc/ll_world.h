@@ -59,6 +59,7 @@ struct World {
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
+    Contact tmp;              // the contact being updated (b2Contact::Update works on it through a reference: with the World record in LDS it stays out of scratch)
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;
 #endif
@@ -238,7 +239,8 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
             continue;
         }
         if (LL_WHATIF(w, WI_NO_COLLIDE_UPDATE)) continue;
-        Contact c = ct_get(w.cs, order[k]);
+        Contact& c = w.tmp;
+        c = ct_get(w.cs, order[k]);
         contact_update(w, tab, c);
         ct_put(w.cs, order[k], c);
     }
@@ -1088,7 +1090,8 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
         if (budget > 0) --budget;
 
-        Contact minContact = ct_get(w.cs, minSlot);
+        Contact& minContact = w.tmp;
+        minContact = ct_get(w.cs, minSlot);
         const int dyn = minContact.body;
         Body& bB = w.b[dyn];
         Sweep backup = bB.sw;
@@ -1123,7 +1126,8 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         }
         if (LL_WHATIF(w, WI_NO_TOI_OTHER_UPDATES)) n_upd = 0;
         for (int j = 0; j < n_upd; ++j) {
-            Contact c = ct_get(w.cs, upd[j]);
+            Contact& c = w.tmp;   // (the impacting contact has been put back by now)
+            c = ct_get(w.cs, upd[j]);
             contact_update(w, tab, c);
             if (c.enabled && c.touching) { c.islandFlag = true; islandSlots[nc++] = upd[j]; }
             ct_put(w.cs, upd[j], c);
