@@ -290,14 +290,17 @@ LLD int clip_segment(ClipV vOut[2], const ClipV vIn[2], V2 normal, float offset,
 }
 
 // b2CollideEdgeAndPolygon (v2.4.1 form), two-sided edge in the ground frame (xfA = identity => xf = xfB)
-LL_NOINLINE void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab, int pi, Xf xfB) {
+// `tmp`: room for 2 * kMaxPoly vectors (the polygon's vertices and normals in the edge's frame, indexed at run time) supplied by
+// the caller — World::poly_tmp, which is LDS when the World record is (a local array here would be scratch memory)
+LL_NOINLINE void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab, int pi, Xf xfB, V2* tmp) {
     manifold.pointCount = 0;
     const Xf xf = xfB;
     V2 edge1 = v2 - v1;
     normalize(edge1);
     V2 normal1 = mk(edge1.y, -edge1.x);
     const int tcount = tab.count[pi];
-    V2 tv[kMaxPoly], tn[kMaxPoly];
+    V2* const tv = tmp;
+    V2* const tn = tmp + kMaxPoly;
     for (int i = 0; i < tcount; ++i) {
         tv[i] = xmul(xf, tab.v[pi][i]);
         tn[i] = rmul(xf.q, tab.n[pi][i]);

@@ -59,6 +59,7 @@ struct World {
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
+    V2 poly_tmp[2 * kMaxPoly];  // collide_edge_polygon's transformed polygon (see there)
     Contact tmp;              // the contact being updated (b2Contact::Update works on it through a reference: with the World record in LDS it stays out of scratch)
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;
@@ -184,7 +185,7 @@ LLD void contact_update(World& w, const PolyTab& tab, Contact& c) {  // b2Contac
     bool wasTouching = c.touching;
     V2 v1, v2;
     edge_verts(w, c.edge, v1, v2);
-    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), w.b[c.body].xf);
+    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), w.b[c.body].xf, w.poly_tmp);
     bool touching = c.m.pointCount > 0;
     for (int i = 0; i < c.m.pointCount; ++i) {
         MPoint& mp2 = c.m.points[i];
@@ -736,7 +737,7 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
     if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
     if (cs.count > 2) { r2 = cs.vc[2 * cs.vs]; rb2 = r2.indexB; }
-    if (cs.count > 3) { r3 = cs.vc[3 * cs.vs]; rb3 = r3.indexB; }
+    if (cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }   // (the fourth may live in the far workspace)
     LL_DIAG_SWEEP_BEGIN(0);
     for (int it = 0; it < LL_WI_LIMIT(180); ++it) {
         if (leg1_first) {
@@ -773,7 +774,7 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     if (rb0 >= 0) cs.vc[0] = r0;
     if (rb1 >= 0) cs.vc[n_vs] = r1;
     if (rb2 >= 0) cs.vc[2 * n_vs] = r2;
-    if (rb3 >= 0) cs.vc[3 * n_vs] = r3;
+    if (rb3 >= 0) cs_vc(cs, 3) = r3;
     J0_io = J0; J1_io = J1; vel_io = vel;
 }
 
