@@ -60,6 +60,7 @@ struct World {
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
     V2 poly_tmp[2 * kMaxPoly];  // collide_edge_polygon's transformed polygon (see there)
+    uint8_t idx[3][kSlots];     // slot lists walked with run-time indices: [0] contact order, [1] evaluations / updates / island contacts, [2] sub-step island
     Contact tmp;              // the contact being updated (b2Contact::Update works on it through a reference: with the World record in LDS it stays out of scratch)
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;
@@ -207,7 +208,8 @@ LLD void contact_update(World& w, const PolyTab& tab, Contact& c) {  // b2Contac
 }
 
 // contact list order: newest first
-LLD int contact_order(const World& w, int* order) {
+template <typename I>
+LLD int contact_order(const World& w, I* order) {
     // rank of a contact = the number of contacts created after it; keys and sequence numbers are read once with
     // static indices (registers), so nothing here waits on a chain of dependent loads
     uint32_t key[kSlots], seq[kSlots];
@@ -220,14 +222,14 @@ LLD int contact_order(const World& w, int* order) {
         int rank = 0;
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) rank += ((key[t] & CK_EXISTS) && seq[t] > seq[s]) ? 1 : 0;
-        order[rank] = s;
+        order[rank] = (I)s;
         ++n;
     }
     return n;
 }
 
 LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
-    int order[kSlots];
+    uint8_t* const order = w.idx[0];
     int n = contact_order(w, order);
     for (int k = 0; k < n; ++k) {
         const uint32_t key = ct_key(w.cs, order[k]);
@@ -319,7 +321,8 @@ LLD bool pos_same(const Pos& a, const Pos& b) {
     return as_u32(a.c.x) == as_u32(b.c.x) && as_u32(a.c.y) == as_u32(b.c.y) && as_u32(a.a) == as_u32(b.a);
 }
 
-LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const int* slots, int count, bool warmStarting, float dtRatio) {
+template <typename I>
+LLD void cs_init(CSolver& s, const CSolverMem& mem, World& w, const LLConst& k, const I* slots, int count, bool warmStarting, float dtRatio) {
     s.vc = mem.vc; s.vs = mem.vc_stride; s.nl = mem.vc_near; s.vo = mem.vc_far; s.vos = mem.vc_far_stride; s.pc = mem.pc; s.ps = mem.pc_stride;
     if (count > mem.cap) { w.overflow |= 2u; count = mem.cap; }
     s.count = count;
@@ -736,8 +739,8 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     int rb0 = -1, rb1 = -1, rb2 = -1, rb3 = -1;
     if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
     if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
-    if (cs.count > 2) { r2 = cs.vc[2 * cs.vs]; rb2 = r2.indexB; }
-    if (cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }   // (the fourth may live in the far workspace)
+    if (cs.count > 2) { r2 = cs_vc(cs, 2); rb2 = r2.indexB; }   // (the third and fourth may live in the far workspace)
+    if (cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }
     LL_DIAG_SWEEP_BEGIN(0);
     for (int it = 0; it < LL_WI_LIMIT(180); ++it) {
         if (leg1_first) {
@@ -773,7 +776,7 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     LL_DIAG_SWEEP_END(0);
     if (rb0 >= 0) cs.vc[0] = r0;
     if (rb1 >= 0) cs.vc[n_vs] = r1;
-    if (rb2 >= 0) cs.vc[2 * n_vs] = r2;
+    if (rb2 >= 0) cs_vc(cs, 2) = r2;
     if (rb3 >= 0) cs_vc(cs, 3) = r3;
     J0_io = J0; J1_io = J1; vel_io = vel;
 }
@@ -918,11 +921,12 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
     if (seed < 0) return;
 
     // depth-first search with Box2D's stack discipline (ground = 3 on the stack)
-    int ibody[3], nb = 0, icontact[kSlots], nc = 0, ijoint[2], nj = 0;
+    int ibody[3], nb = 0, nc = 0, ijoint[2], nj = 0;
+    uint8_t* const icontact = w.idx[1];
     int cstart[4] = {0, 0, 0, 0};  // constraints of the q-th visited body: [cstart[q], cstart[q + 1])
     bool jflag[2] = {false, false}, groundFlag = false;
     int stack[6], sc = 0;
-    int order[kSlots];
+    uint8_t* const order = w.idx[0];
     const int n_order = contact_order(w, order);
     stack[sc++] = seed; w.b[seed].islandFlag = true;
     while (sc > 0) {
@@ -1039,7 +1043,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
     float gA = w.gA;
     // the contact list, newest first: SolveTOI only ever adds contacts (FindNewContacts after a sub-step), so the
     // order is rebuilt when the sequence counter has moved and not on every pass
-    int order[kSlots];
+    uint8_t* const order = w.idx[0];
     int n_order = contact_order(w, order);
     uint32_t order_seq = w.next_seq;
     for (;;) {
@@ -1051,7 +1055,8 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         // per-contact order and arithmetic: (1) list the contacts that need a computation, (2) compute them —
         // lanes of a wave need different list positions, and one pass over the compacted list runs
         // time_of_impact max-over-lanes(own count) times instead of once per list position — (3) take the minimum.
-        int need[kSlots], n_need = 0;
+        uint8_t* const need = w.idx[1];
+        int n_need = 0;
         for (int q = 0; q < n_order; ++q) {
             const uint32_t key = ct_key(w.cs, order[q]);
             if (!(key & CK_ENABLED) || ck_toi_count(key) > b2_maxSubSteps || (key & CK_TOIFLAG)) continue;
@@ -1113,13 +1118,15 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         body_set_awake(bB, true);
         LL_STAMP(17);
 
-        int islandSlots[kSlots], nc = 0;
+        uint8_t* const islandSlots = w.idx[2];
+        int nc = 0;
         islandSlots[nc++] = minSlot;
         minContact.islandFlag = true;
         ct_put(w.cs, minSlot, minContact);
         // the body's other contacts, in list order; listed first so that the lanes of a wave run contact_update once per
         // list position of their own (an update changes no other contact's key)
-        int upd[kSlots], n_upd = 0;
+        uint8_t* const upd = w.idx[1];   // (the list of evaluations has been consumed)
+        int n_upd = 0;
         for (int q = 0; q < n_order; ++q) {
             const uint32_t key = ct_key(w.cs, order[q]);
             if (!(key & CK_EXISTS) || ck_body(key) != dyn || (key & CK_ISLAND)) continue;

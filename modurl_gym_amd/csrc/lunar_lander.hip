@@ -231,7 +231,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // constraints + 4.6 KB staged contact words + 16.8 KB World + table = 36.9 KB (four blocks per CU); with the working contact and
     // collide_edge_polygon's polygon buffer added to the World record and 3 constraints per lane: 40.0 KB.
     constexpr bool kWorldLds = BLK <= 32;
-    constexpr int kVcNear = kWorldLds ? kVcNearLds - 1 : kVcNearLds;
+    constexpr int kVcNear = kWorldLds ? kVcNearLds - 2 : kVcNearLds;
     __shared__ World s_world[kWorldLds ? BLK : 1];
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kVcNear * BLK];
@@ -661,7 +661,7 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
         dev.kd = static_cast<const LLConst*>(kdev);
         // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
-        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds + 1) * work_grid().x * 64 * sizeof(VConstraint)));
+        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds + 2) * work_grid().x * 64 * sizeof(VConstraint)));
         dev.vc_far = static_cast<VConstraint*>(vc_far_base);
         {   // the helper stream carries the work that is NOT on the critical path: lowest priority (1 Mi envs: 3.65 -> 3.52 ms per step)
             int lo = 0, hi = 0;

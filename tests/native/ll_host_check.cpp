@@ -69,8 +69,8 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 8; ++q) { total++; if (state[q] == oobs[q * n + i]) exact++; if (!closef(state[q], oobs[q * n + i])) { if (mism < 10) printf("reset env %lu obs[%d] %.9g vs %.9g\n", (unsigned long)i, q, state[q], oobs[q * n + i]); mism++; } }
     }
     VConstraint h_vc[kSlots]; PConstraint h_pc[kSlots];
-    VConstraint h_vc_far[kSlots];  // constraints 3.. go through the far (global workspace) path here, as in the 32-lane blocks on the GPU (64-lane blocks: 4..)
-    CSolverMem mem; mem.vc = h_vc; mem.vc_stride = 1; mem.vc_near = 3; mem.vc_far = h_vc_far; mem.vc_far_stride = 1; mem.pc = h_pc; mem.pc_stride = 1; mem.cap = kSlots;
+    VConstraint h_vc_far[kSlots];  // constraints 2.. go through the far (global workspace) path here, as in the 32-lane blocks on the GPU (64-lane blocks: 4..)
+    CSolverMem mem; mem.vc = h_vc; mem.vc_stride = 1; mem.vc_near = 2; mem.vc_far = h_vc_far; mem.vc_far_stride = 1; mem.pc = h_pc; mem.pc_stride = 1; mem.cap = kSlots;
     uint32_t rs = 12345;
     for (int t = 0; t < steps; ++t) {
         for (uint64_t i = 0; i < n; ++i) { rs = rs * 1664525u + 1013904223u; act[i] = (rs >> 16) & 3u; }
