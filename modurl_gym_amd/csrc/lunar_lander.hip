@@ -225,11 +225,11 @@ template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
-    // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes: 536 B per lane,
-    // indexed by body / edge at run time) in LDS instead of scratch: ~100 cycles per dependent access instead of >= 500, and
-    // 450 B less scratch per lane (1.45 -> 1.40 ms per step at 262 144 envs).  LDS of a 32-lane block: 4 x 32 x 124 B
-    // constraints + 4.6 KB staged contact words + 16.8 KB World + table = 36.9 KB (four blocks per CU); with the working contact and
-    // collide_edge_polygon's polygon buffer added to the World record and 3 constraints per lane: 40.0 KB.
+    // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
+    // being updated, collide_edge_polygon's polygon buffer, the slot lists: 720 B per lane, all indexed at run time) in LDS
+    // instead of scratch: ~100 cycles per dependent access instead of >= 500 (1.45 -> 1.29 ms per step at 262 144 envs,
+    // scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
+    // 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
     constexpr bool kWorldLds = BLK <= 32;
     constexpr int kVcNear = kWorldLds ? kVcNearLds - 2 : kVcNearLds;
     __shared__ World s_world[kWorldLds ? BLK : 1];
