@@ -46,6 +46,15 @@ struct Joint {  // b2RevoluteJoint, bodyA = lander (0), bodyB = leg (1 + j)
     float invDetK;  // 1/det(K) (or det when it is 0) exactly as b2Mat22::Solve forms it: K is fixed for the whole velocity solve
 };
 
+// Working storage of a step that is indexed at run time or handed to an out-of-line function by reference — as local
+// variables these would be scratch memory (>= 500 cycles per dependent access); every kernel that runs the contact path
+// keeps one per lane in LDS (224 B), whatever it does with the World record itself.
+struct WorldTmp {
+    Contact tmp;                // the contact being updated (b2Contact::Update works on it through a reference)
+    V2 poly_tmp[2 * kMaxPoly];  // collide_edge_polygon's transformed polygon (see there)
+    uint8_t idx[3][kSlots];     // slot lists: [0] contact order, [1] evaluations / updates / island contacts, [2] sub-step island
+};
+
 struct World {
     Body b[3];
     CtStore cs;             // the env's contact-cache slots, in place in the engine's columns (ll_b2.h)
@@ -59,9 +68,7 @@ struct World {
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
-    V2 poly_tmp[2 * kMaxPoly];  // collide_edge_polygon's transformed polygon (see there)
-    uint8_t idx[3][kSlots];     // slot lists walked with run-time indices: [0] contact order, [1] evaluations / updates / island contacts, [2] sub-step island
-    Contact tmp;              // the contact being updated (b2Contact::Update works on it through a reference: with the World record in LDS it stays out of scratch)
+    LL_LDS WorldTmp* t;       // per-lane working storage in LDS (below)
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;
 #endif
@@ -186,7 +193,7 @@ LLD void contact_update(World& w, const PolyTab& tab, Contact& c) {  // b2Contac
     bool wasTouching = c.touching;
     V2 v1, v2;
     edge_verts(w, c.edge, v1, v2);
-    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), w.b[c.body].xf, w.poly_tmp);
+    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), w.b[c.body].xf, (V2*)w.t->poly_tmp);
     bool touching = c.m.pointCount > 0;
     for (int i = 0; i < c.m.pointCount; ++i) {
         MPoint& mp2 = c.m.points[i];
@@ -229,7 +236,7 @@ LLD int contact_order(const World& w, I* order) {
 }
 
 LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
-    uint8_t* const order = w.idx[0];
+    uint8_t* const order = (uint8_t*)w.t->idx[0];
     int n = contact_order(w, order);
     for (int k = 0; k < n; ++k) {
         const uint32_t key = ct_key(w.cs, order[k]);
@@ -242,7 +249,7 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
             continue;
         }
         if (LL_WHATIF(w, WI_NO_COLLIDE_UPDATE)) continue;
-        Contact& c = w.tmp;
+        Contact& c = *(Contact*)&w.t->tmp;
         c = ct_get(w.cs, order[k]);
         contact_update(w, tab, c);
         ct_put(w.cs, order[k], c);
@@ -922,11 +929,11 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
 
     // depth-first search with Box2D's stack discipline (ground = 3 on the stack)
     int ibody[3], nb = 0, nc = 0, ijoint[2], nj = 0;
-    uint8_t* const icontact = w.idx[1];
+    uint8_t* const icontact = (uint8_t*)w.t->idx[1];
     int cstart[4] = {0, 0, 0, 0};  // constraints of the q-th visited body: [cstart[q], cstart[q + 1])
     bool jflag[2] = {false, false}, groundFlag = false;
     int stack[6], sc = 0;
-    uint8_t* const order = w.idx[0];
+    uint8_t* const order = (uint8_t*)w.t->idx[0];
     const int n_order = contact_order(w, order);
     stack[sc++] = seed; w.b[seed].islandFlag = true;
     while (sc > 0) {
@@ -1043,7 +1050,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
     float gA = w.gA;
     // the contact list, newest first: SolveTOI only ever adds contacts (FindNewContacts after a sub-step), so the
     // order is rebuilt when the sequence counter has moved and not on every pass
-    uint8_t* const order = w.idx[0];
+    uint8_t* const order = (uint8_t*)w.t->idx[0];
     int n_order = contact_order(w, order);
     uint32_t order_seq = w.next_seq;
     for (;;) {
@@ -1055,7 +1062,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         // per-contact order and arithmetic: (1) list the contacts that need a computation, (2) compute them —
         // lanes of a wave need different list positions, and one pass over the compacted list runs
         // time_of_impact max-over-lanes(own count) times instead of once per list position — (3) take the minimum.
-        uint8_t* const need = w.idx[1];
+        uint8_t* const need = (uint8_t*)w.t->idx[1];
         int n_need = 0;
         for (int q = 0; q < n_order; ++q) {
             const uint32_t key = ct_key(w.cs, order[q]);
@@ -1096,7 +1103,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
         if (budget > 0) --budget;
 
-        Contact& minContact = w.tmp;
+        Contact& minContact = *(Contact*)&w.t->tmp;
         minContact = ct_get(w.cs, minSlot);
         const int dyn = minContact.body;
         Body& bB = w.b[dyn];
@@ -1118,14 +1125,14 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         body_set_awake(bB, true);
         LL_STAMP(17);
 
-        uint8_t* const islandSlots = w.idx[2];
+        uint8_t* const islandSlots = (uint8_t*)w.t->idx[2];
         int nc = 0;
         islandSlots[nc++] = minSlot;
         minContact.islandFlag = true;
         ct_put(w.cs, minSlot, minContact);
         // the body's other contacts, in list order; listed first so that the lanes of a wave run contact_update once per
         // list position of their own (an update changes no other contact's key)
-        uint8_t* const upd = w.idx[1];   // (the list of evaluations has been consumed)
+        uint8_t* const upd = (uint8_t*)w.t->idx[1];   // (the list of evaluations has been consumed)
         int n_upd = 0;
         for (int q = 0; q < n_order; ++q) {
             const uint32_t key = ct_key(w.cs, order[q]);
@@ -1134,7 +1141,7 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         }
         if (LL_WHATIF(w, WI_NO_TOI_OTHER_UPDATES)) n_upd = 0;
         for (int j = 0; j < n_upd; ++j) {
-            Contact& c = w.tmp;   // (the impacting contact has been put back by now)
+            Contact& c = *(Contact*)&w.t->tmp;   // (the impacting contact has been put back by now)
             c = ct_get(w.cs, upd[j]);
             contact_update(w, tab, c);
             if (c.enabled && c.touching) { c.islandFlag = true; islandSlots[nc++] = upd[j]; }

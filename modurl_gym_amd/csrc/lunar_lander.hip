@@ -47,9 +47,12 @@ constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no in
 #define LL_SOLVER_CAP 9
 #endif
 constexpr int kSolverCap = LL_SOLVER_CAP;
-constexpr int kVcNearLds = 4;  // of those, kept in LDS by the contact kernel (4 blocks per CU in either block size); the rest in LLDev::vc_far
+constexpr int kVcNearLds = 2;  // of those, kept in LDS by the contact kernel (4 blocks per CU in either block size; the sweeps hold the first four in registers anyway); the rest in LLDev::vc_far
 // the staged KEY / SEQ / TOI words of the contact cache (ll_b2.h CtHot): one LDS column per lane of the block
 #define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ), 1u}
+// the per-lane working storage of the contact path (ll_world.h WorldTmp): one LDS record per lane of the block
+#define LL_TMP_DECL(BLKSZ) __shared__ WorldTmp s_tmp[(BLKSZ)]
+#define LL_TMP_PTR() ((LL_LDS WorldTmp*)s_tmp + threadIdx.x)
 constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
 // Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
 //   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
@@ -231,8 +234,9 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
     // 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
     constexpr bool kWorldLds = BLK <= 32;
-    constexpr int kVcNear = kWorldLds ? kVcNearLds - 2 : kVcNearLds;
+    constexpr int kVcNear = kVcNearLds;
     __shared__ World s_world[kWorldLds ? BLK : 1];
+    LL_TMP_DECL(BLK);
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kVcNear * BLK];
     __shared__ uint32_t s_hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
@@ -267,6 +271,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
             }
             World w_local;
             World& w = kWorldLds ? s_world[kWorldLds ? threadIdx.x : 0] : w_local;
+            w.t = LL_TMP_PTR();
             EnvRegs e;
             ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
@@ -314,6 +319,7 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kSolverCap * BLK];
     LL_HOT_DECL(BLK);
+    LL_TMP_DECL(BLK);
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
@@ -329,6 +335,7 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
         if (q < total) {
             i = list[q];
             World w; EnvRegs e;
+            w.t = LL_TMP_PTR();
             ll_load(d, i, w, e, hot, true);
             if (ll_step_continue(w, tab, LLK(d), mem, budget)) {
                 float state[8], reward; uint32_t done;
@@ -362,6 +369,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
     // velocity constraints of the contact solver: LDS, one column per lane (31-word records: conflict-free)
     __shared__ VConstraint s_vc[kSolverCap * BLK];
     LL_HOT_DECL(BLK);
+    LL_TMP_DECL(BLK);
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
@@ -379,6 +387,7 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
         int mode = forced;
         if (list) { uint32_t ent = list[q]; i = ent & ~kWorkReset; mode = (ent & kWorkReset) ? 1 : 0; }
         World w; EnvRegs e;
+        w.t = LL_TMP_PTR();
         ll_load(d, i, w, e, hot);
         float state[8];
         if (mode == 0 && !e.has_world) {
@@ -456,6 +465,7 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
             V2 force; float torque;
             {
                 World w; EnvRegs e;
+                w.t = nullptr;  // (a reset never reaches the contact path)
                 ll_load(d, i, w, e, hot);
                 ll_reset_scene(d, i, w, e, tab);
                 force = w.b[0].force; torque = w.b[0].torque;  // the initial random push (:845-849) is not a state column
@@ -567,6 +577,7 @@ __global__ void __launch_bounds__(kLLBlock) ll_import_kernel(LLDev d, const uint
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
     World w; EnvRegs e;
+    w.t = nullptr;
     ll_load(d, i, w, e, hot);
     if (e.has_world) {
         float raw[18];
@@ -661,7 +672,7 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
         dev.kd = static_cast<const LLConst*>(kdev);
         // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
-        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds + 2) * work_grid().x * 64 * sizeof(VConstraint)));
+        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds) * work_grid().x * 64 * sizeof(VConstraint)));
         dev.vc_far = static_cast<VConstraint*>(vc_far_base);
         {   // the helper stream carries the work that is NOT on the critical path: lowest priority (1 Mi envs: 3.65 -> 3.52 ms per step)
             int lo = 0, hi = 0;

@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);
     std::vector<uint32_t> act(n);
     if (deterministic) ora_vec_reset_deterministic(ov, oobs.data()); else ora_vec_reset(ov, NULL, oobs.data(), 1);
+    WorldTmp h_tmp;  // the per-lane working storage (LDS on the GPU)
     uint32_t h_hot[3 * kSlots]; const CtHot hot{h_hot, 1u, toi_staged};  // the staged KEY / SEQ / TOI words (LDS on the GPU)
     VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
     CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.vc_near = kSlots; mem0.vc_far = nullptr; mem0.vc_far_stride = 0; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
     for (uint64_t i = 0; i < n; ++i) {
         World w; EnvRegs e; float state[8];
+        w.t = &h_tmp;
         ll_load(d, i, w, e, hot);
         if (deterministic) {
             float height[12]; for (int q = 0; q < 12; ++q) height[q] = (400.0f / 30.0f) / 8.0f;
@@ -90,6 +92,7 @@ int main(int argc, char** argv) {
                 // time-of-impact evaluation, then one sub-step per "launch", the environment going through its
                 // mid-step columns (ll_store / ll_load with mid = true) in between, as on the GPU
                 World w; EnvRegs e;
+                w.t = &h_tmp;
 #ifdef LL_HOST_STATS
                 const uint32_t flags0 = d.st[(uint64_t)C_FLAGS * d.n_pad + i];
                 const int touching0 = (flags0 & F_TOUCHING) ? 1 : 0, ncont0 = (int)((flags0 >> F_NCONTACT_SHIFT) & 15u);
@@ -101,6 +104,7 @@ int main(int argc, char** argv) {
                 while (!fin) {
                     ll_store(d, i, w, e, true);
                     World w2; EnvRegs e2;
+                    w2.t = &h_tmp;
                     ll_load(d, i, w2, e2, hot, true);
                     w2.overflow |= w.overflow;
                     w = w2; e = e2;
@@ -131,7 +135,7 @@ int main(int argc, char** argv) {
         }
         if (t % 2 == 0 && !deterministic) {  // masked reset of finished envs on both sides
             ora_vec_reset(ov, mask.data(), NULL, 1);
-            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; ll_load(d, i, w, e, hot); ll_env_reset(d, i, w, e, tab, mem, state); ll_store(d, i, w, e); }
+            for (uint64_t i = 0; i < n; ++i) if (mask[i]) { World w; EnvRegs e; float state[8]; w.t = &h_tmp; ll_load(d, i, w, e, hot); ll_env_reset(d, i, w, e, tab, mem, state); ll_store(d, i, w, e); }
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
