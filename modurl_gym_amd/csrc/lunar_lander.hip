@@ -641,12 +641,11 @@ struct LunarLanderEnv final : Env {
     int init() override {
         // Contact-kernel block size and launch order (profiles/r02_lunarlander/population_block_overlap_matrix.txt, ms per step,
         // 32-lane / 64-lane blocks, sequential -> overlapped order):
-        //     131 072 envs  1.58 -> 1.43 / 1.67 -> 1.54        524 288 envs  2.90 -> 2.71 / 2.38 -> 1.87
-        //     262 144 envs  1.82 -> 1.52 / 1.94 -> 1.71      1 048 576 envs  4.85 -> 4.91 / 3.99 -> 3.66
-        //     393 216 envs  2.55 -> 2.15 / 2.20 -> 1.79      2 097 152 envs  8.64 -> 8.71 / 7.02 -> 6.78
+        //     131 072 envs  1.47 -> 1.26 / 1.62 -> 1.39        524 288 envs  2.60 -> 2.09 / 2.35 -> 1.73
+        //     262 144 envs  1.64 -> 1.30 / 1.89 -> 1.55      2 097 152 envs  7.59 -> 7.74 / 6.82 -> 6.16
         // 32-lane blocks (which also afford the World record in LDS) give the shortest waves: best while the whole
         // worklist is co-resident.  Beyond that the kernel is bound by wave slots — one 512-register wave per SIMD, four
-        // blocks per CU by LDS — and 64-lane blocks (4 constraints per lane in LDS, the rest in LLDev::vc_far) carry twice
+        // blocks per CU by LDS — and 64-lane blocks (World record in scratch, working storage in LDS) carry twice
         // the environments per slot.  The overlapped order (contact kernel beside the free-flight kernel, see step()) pays
         // at every size once the blocks are chosen this way.
         if (gen_block == 0) gen_block = n >= 327680 ? 64 : 32;
