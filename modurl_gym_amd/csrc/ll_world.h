@@ -257,11 +257,12 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
 }
 
 // ---- contact solver over a list of slots --------------------------------------------------------------
-// Constraint storage is supplied by the caller: on the GPU the velocity constraints live in LDS, one
-// column per lane (element i of lane l at vc[i * stride], stride = 64), the position constraints in local
-// memory; the host test passes plain arrays with stride 1.
-// The first `vc_near` velocity constraints of a lane live in `vc` (LDS), the rest — rarely more than a few exist —
-// in `vc_far` (a global workspace): a 64-lane block affords 5 constraints per lane in LDS at four blocks per CU.
+// Constraint storage is supplied by the caller.  On the GPU the first `vc_near` velocity constraints of a lane live in
+// LDS, one column per lane (element i of lane l at vc[i * stride], stride = lanes per block), the rest — rarely more
+// than a few exist — in `vc_far` (a global workspace, one column per lane of the grid): LDS is worth more to the
+// run-time-indexed per-lane records (lunar_lander.hip) than to constraints the sweeps hold in registers anyway
+// (vc_near >= 2: toi_sweeps reads vc[0], vc[stride] directly).  The position constraints are local memory.
+// The host test passes plain arrays with stride 1.
 struct CSolverMem { VConstraint* vc; int vc_stride; int vc_near; VConstraint* vc_far; int vc_far_stride; PConstraint* pc; int pc_stride; int cap; };
 struct CSolver {
     VConstraint* vc; int vs;
