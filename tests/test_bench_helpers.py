@@ -38,6 +38,13 @@ def test_source_hash_ignores_comments_but_not_code():
     assert code_only(a) == code_only(b) != code_only(c)
 
 
+def test_launch_mode_per_family():
+    # --launch auto: hipGraph replay for the launch-bound families, eager launches for LunarLander
+    assert bench.launch_mode("auto", "cartpole") == "graph" and bench.launch_mode("auto", "mountain_car_cont") == "graph"
+    assert bench.launch_mode("auto", "lunar_lander") == "eager"
+    assert bench.launch_mode("graph", "lunar_lander") == "graph" and bench.launch_mode("eager", "cartpole") == "eager"
+
+
 def test_host_cores_follows_affinity_and_override(monkeypatch):
     n = bench.host_cores()
     assert 1 <= n <= 64 and n <= len(os.sched_getaffinity(0))
