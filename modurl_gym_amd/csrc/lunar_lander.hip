@@ -16,8 +16,12 @@
 //   ll_contact_kernel<32|64>    contact path (Collide, island solve, SolveTOI) over that list      caller's stream
 //   ll_free_kernel              register-only step of everyone else, beside it                     helper stream
 //   ll_contact_kernel<32>       the few envs the free-flight kernel declined                       helper stream
-//   ll_reset_kernel<32>         fused auto-reset of the finished envs, after the join              caller's stream
-// MGYM_LL_OVERLAP=0 runs the same kernels one after the other (free-flight kernel first: it then builds the list).
+//   ll_apply_select / _copy     fused auto-reset of the finished envs, after the join: the state of       caller's stream
+//                               their next episode was prepared in shadow columns and is copied in
+//   ll_reset_kernel<32>         prepares the NEXT reset of those envs, beside the following step          second helper stream
+// MGYM_LL_OVERLAP=0 runs the step kernels one after the other (free-flight kernel first: it then builds the list);
+// MGYM_LL_STAGED_RESET=0 (and populations from 327 680 envs, and steps captured into a hipGraph) compute a reset when
+// the episode ends (ll_reset_kernel on the caller's stream).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
