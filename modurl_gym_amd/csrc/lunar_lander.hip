@@ -20,7 +20,7 @@
 //                               their next episode was prepared in shadow columns and is copied in
 //   ll_reset_kernel<32>         prepares the NEXT reset of those envs, beside the following step          second helper stream
 // MGYM_LL_OVERLAP=0 runs the step kernels one after the other (free-flight kernel first: it then builds the list);
-// MGYM_LL_STAGED_RESET=0 (and populations from 327 680 envs, and steps captured into a hipGraph) compute a reset when
+// MGYM_LL_STAGED_RESET=0 (and populations from 524 288 envs, and steps captured into a hipGraph) compute a reset when
 // the episode ends (ll_reset_kernel on the caller's stream).
 #include <math.h>
 #include <stdlib.h>
@@ -652,7 +652,7 @@ struct LunarLanderEnv final : Env {
         // blocks per CU by LDS — and 64-lane blocks (World record in scratch, working storage in LDS) carry twice
         // the environments per slot.  The overlapped order (contact kernel beside the free-flight kernel, see step()) pays
         // at every size once the blocks are chosen this way.
-        if (gen_block == 0) gen_block = n >= 327680 ? 64 : 32;
+        if (gen_block == 0) gen_block = n >= 360448 ? 64 : 32;   // (327 680 envs: 1.42 / 1.60 ms with 32- / 64-lane blocks; 393 216: 1.84 / 1.60)
         if (overlap < 0) overlap = 1;
         obs_dim = 8;
         state_cols = 27;
@@ -689,10 +689,10 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         dev.split = 0;
         dev.prep = 0; dev.episode_src = nullptr;
-        // (pays while the step is bound by the contact kernel's chain: 131 072 envs 1.43 -> 1.36 ms per step, 262 144 1.50 -> 1.46;
-        // a population that fills every wave slot gains nothing from moving the reset work and loses to the extra launches:
-        // 1 Mi envs 3.53 -> 3.84; MGYM_LL_STAGED_RESET=2 forces it on)
-        staged = (staged == 2 || (staged == 1 && n < 327680)) && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
+        // (pays while the step is bound by the contact kernel's chain: 131 072 envs 1.43 -> 1.36 ms per step, 262 144 1.50 -> 1.46,
+        // 393 216 1.67 -> 1.60; a population that fills every wave slot gains nothing from moving the reset work and loses to the
+        // extra launches: 524 288 envs 1.86 -> 1.83, 1 Mi envs 3.53 -> 3.84; MGYM_LL_STAGED_RESET=2 forces it on)
+        staged = (staged == 2 || (staged == 1 && n < 524288)) && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
         if (staged) {
             MGYM_HIP(hipMalloc(&shadow_base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
             MGYM_HIP(hipMemsetAsync(shadow_base, 0, (size_t)C_COUNT * n_pad * sizeof(uint32_t), stream));
