@@ -26,10 +26,8 @@ import os
 import sys
 import time
 
-# The HIP runtime gives a process 4 hardware queues per device by default and lets further streams share them; streams that
-# share a queue run one after the other.  This bench keeps up to three family streams plus LunarLander's helper stream (and
-# torch's own) alive at once, and the overlaps it measures must be real ones: ask for 8 (a runtime knob of ROCclr, read at init).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (The hardware-queue setting the LunarLander helper streams need — GPU_MAX_HW_QUEUES — is owned by the package:
+# modurl_gym_amd/__init__.py sets it before anything initialises HIP; bench.py imports the package before torch touches the GPU.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -59,7 +57,49 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="rehearse the multi-process launch without a GPU: every rank joins a gloo group, rank 0 prints one JSON line "
+                         "listing the RANK/LOCAL_RANK/WORLD_SIZE each rank saw")
     return ap.parse_args()
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves.
+
+    The reference is single-threaded and `!Send` (src/box_2d/lunar_lander.rs:240-249), so the split over GPUs is this build's to
+    own.  Runs BEFORE torch is imported or HIP is touched, starts `python -m torch.distributed.run` as a CHILD process (never an
+    exec: a process that has initialised the GPU must not be replaced), lets the child's rank 0 write the single JSON line to the
+    stdout we share with it, and returns the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:   # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")   # (torchrun sets it anyway and says so on stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run_launch(args, rank, local_rank, world, real_stdout):
+    """--dry-run-launch: the launch plumbing without a GPU (gloo): every rank reports the env it was given."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.tensor([rank, local_rank, world, int(os.environ.get("WORLD_SIZE", "-1"))], dtype=torch.int64)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        line = {"dry_run_launch": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ranks": [{"RANK": int(t[0]), "LOCAL_RANK": int(t[1]), "WORLD_SIZE": int(t[3])} for t in seen]}
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
 def launch_mode(requested, family):
@@ -255,6 +295,8 @@ def cpu_baseline(workload, n, seed):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # no launcher around us: start the ranks as a child torchrun (before torch / HIP are touched)
     # The contract is ONE JSON line on stdout.  Native libraries print banners there (RCCL's version block at communicator
     # creation): point fd 1 at stderr for the run and keep the real stdout for the result line.
     sys.stdout.flush()
@@ -264,14 +306,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
-        args.gpus = world
+        args.gpus = world   # the launcher's world size wins (N > 1 without a launcher never gets here: self_launch)
+    if args.dry_run_launch:
+        dry_run_launch(args, rank, local_rank, world, real_stdout)
+        return
 
+    import modurl_gym_amd as mg   # first: it asks for the hardware queues before anything initialises HIP
     import torch
-
-    import modurl_gym_amd as mg
 
     if not torch.cuda.is_available() or mg.device_count() == 0:
         print("bench.py: no MI355X visible — the engine has no CPU fallback", file=sys.stderr)

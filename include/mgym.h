@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGYM_ABI_VERSION 2
+#define MGYM_ABI_VERSION 3
 
 typedef struct mgym_env mgym_env;
 
@@ -166,7 +166,20 @@ int mgym_observation(mgym_env *env, const float **obs, uint64_t *col_stride);
 int mgym_observation_aos(mgym_env *env, float *out_aos);
 
 /* Test seam / checkpoint ≙ Testable::set_state (src/testing.rs:15-18).  blob = [state_cols][n_envs]
- * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md. */
+ * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md.
+ *
+ * LIMITS of the CartPole counters (the engine keeps steps_since_reset, steps_beyond_terminated and the per-env
+ * episode number in ONE 32-bit word per env, cartpole_step.h):
+ *  - blob column 4, steps_since_reset, saturates at 1023 and column 5, steps_beyond_terminated, at Some(2): the
+ *    reference only ever tests "steps >= 500" and None/Some (cartpole.rs:297, 319, 330), so no result depends on more;
+ *    larger imported values are clamped.
+ *  - blob column 6, the episode number (= resets of this env so far), is kept MODULO 2^20, on import too.  It is word 2
+ *    of the Philox counter of the env's next reset draw, so after 1 048 576 resets of ONE env its initial states
+ *    repeat from the first one (same seed, same env id).  With a uniform random policy (~22-step episodes) that is
+ *    ~2.3e7 steps of that env — about four minutes at this engine's CartPole rate.  The reference draws from an RNG
+ *    that never cycles in practice (cartpole.rs:240); a trainer that steps one handle past that horizon and needs
+ *    fresh initial states should create the next handle with a new `seed`.  Nothing else depends on the wrap.
+ *    MountainCar and LunarLander keep a full 32-bit episode counter. */
 int mgym_get_state(mgym_env *env, void *blob);
 int mgym_set_state(mgym_env *env, const void *blob);
 
@@ -186,6 +199,17 @@ int mgym_sync(mgym_env *env);
 
 /* Thread-local message for the last failing call on this thread. */
 const char *mgym_last_error(void);
+
+/* Describes how this handle runs, as NUL-terminated "key=value" lines written to buf (at most cap bytes, always terminated;
+ * returns MGYM_ERR_BAD_ARG if cap is too small).  Keys every family reports: kind, n_envs, device, auto_reset,
+ * GPU_MAX_HW_QUEUES (the HIP runtime knob as this process's environment held it when the handle was created, or "unset").
+ * LunarLander adds its launch structure — contact_block, launch_order, staged_resets — and `concurrent_streams`: the
+ * reference is single-threaded (lunar_lander.rs:240-249), this engine steps one population on up to three streams
+ * (caller's stream, two helpers), and they only run side by side when the runtime put them on different hardware queues.
+ * The call launches a ~50 us probe kernel on each of them at once and reports how many were seen running at the same
+ * time (3 of 3 is the measured configuration; fewer: set GPU_MAX_HW_QUEUES=8 before the first HIP call of the
+ * process).  Synchronises the stream. */
+int mgym_get_info(mgym_env *env, char *buf, size_t cap);
 
 /* Plain device-memory helpers for callers without their own HIP allocator (C/C++/ctypes). */
 int mgym_malloc(int device, size_t bytes, void **out);

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mgym_get_spec": (C.c_int, [C.c_int, C.POINTER(Spec)]),
     "mgym_sync": (C.c_int, [_vp]),
     "mgym_last_error": (C.c_char_p, []),
+    "mgym_get_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "mgym_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),
     "mgym_free": (C.c_int, [C.c_int, _vp]),
     "mgym_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t]),
@@ -89,7 +90,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mgym_abi_version() != 2:
+    if lib.mgym_abi_version() != 3:
         raise OSError("libmgym.so ABI version mismatch")
     _lib = lib
     return lib

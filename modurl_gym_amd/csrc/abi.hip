@@ -1,6 +1,7 @@
 // abi.hip — the extern "C" entry points declared in include/mgym.h.
 // Thin: argument checks, device selection, dispatch to the per-family Env object.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -143,6 +144,7 @@ int mgym_create(const mgym_config* cfg, mgym_env** out) {
     }
     if (!impl) { set_last_error("mgym_create: environment family not available in this build"); return MGYM_ERR_BAD_CONFIG; }
     impl->cfg = *cfg;
+    { const char* q = getenv("GPU_MAX_HW_QUEUES"); impl->hwq_env = q ? q : "unset"; }
     impl->kind = cfg->kind;
     impl->n = cfg->n_envs;
     impl->n_pad = round_up(cfg->n_envs ? cfg->n_envs : 1, 1024);
@@ -323,6 +325,19 @@ int mgym_sync(mgym_env* env) {
 }
 
 const char* mgym_last_error(void) { return g_last_error.c_str(); }
+
+int mgym_get_info(mgym_env* env, char* buf, size_t cap) {
+    ENV_OR_FAIL(env);
+    if (!buf || cap == 0) return bad_arg("mgym_get_info: buf is NULL or cap is 0");
+    static const char* const kinds[] = {"cartpole", "mountain_car", "mountain_car_continuous", "lunar_lander"};
+    std::string out = std::string("kind=") + kinds[e->kind] + "\nn_envs=" + std::to_string(e->n) + "\ndevice=" + std::to_string(e->cfg.device) +
+                      "\nauto_reset=" + ((e->cfg.flags & MGYM_FLAG_AUTO_RESET) ? "1" : "0") + "\nGPU_MAX_HW_QUEUES=" + e->hwq_env + "\n";
+    int st = e->info(out);
+    if (st != MGYM_OK) return st;
+    if (out.size() + 1 > cap) { buf[0] = 0; return bad_arg("mgym_get_info: buffer too small"); }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return MGYM_OK;
+}
 
 int mgym_malloc(int device, size_t bytes, void** out) {
     if (!out) return bad_arg("mgym_malloc: NULL");

@@ -75,6 +75,9 @@ struct Env {
     virtual int reset_deterministic(float* obs_out) = 0;
     // helper streams forked from `stream` must have rejoined it before a stream capture ends (mgym_graph_end)
     virtual int join_helpers() { return MGYM_OK; }
+    // mgym_get_info: family-specific "key=value" lines appended to `out` (may launch probe kernels and synchronise)
+    virtual int info(std::string&) { return MGYM_OK; }
+    std::string hwq_env;   // GPU_MAX_HW_QUEUES as the environment held it at mgym_create ("unset" if absent)
     virtual int set_dispersion(const float*) { set_last_error("dispersion override: LunarLander only"); return MGYM_ERR_BAD_ARG; }
 };
 

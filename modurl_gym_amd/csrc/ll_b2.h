@@ -61,7 +61,11 @@ struct AABB { V2 lo, hi; };
 #define LLD __device__ __forceinline__
 // out-of-line device functions (own register allocation; ONE copy of their local arrays in the caller's scratch frame)
 #if defined(__HIPCC__)
+#ifdef LL_CONTACT_NUM_VGPR   // register budget of the contact path (see lunar_lander.hip): the out-of-line functions count towards the kernel's
+#define LL_NOINLINE __device__ __noinline__ __attribute__((amdgpu_num_vgpr(LL_CONTACT_NUM_VGPR)))
+#else
 #define LL_NOINLINE __device__ __noinline__
+#endif
 #else
 #define LL_NOINLINE static
 #endif

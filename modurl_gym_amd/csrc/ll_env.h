@@ -56,6 +56,8 @@ struct LLDev {
                         // by-value kernel argument never has its address taken — otherwise every lane keeps a private copy
                         // of it in scratch (~400 B/lane), and scratch size caps the number of concurrent waves
     VConstraint* vc_far;  // workspace for the velocity constraints that do not fit a block's LDS: [kSolverCap - near][contact-kernel lanes]
+    VConstraint* vc_far_late;  // ... of the late contact launch of the overlapped order (it runs beside the main one: a slice of its own)
+    int vc_near;          // constraints per lane kept in LDS (<= the kernel's LDS array; lower only as a test knob)
     int auto_reset;
     int bucket;  // worklist bucketing by F_TOUCHING
     const uint32_t* episode_src;  // staged resets: this LLDev addresses the SHADOW columns; the episode counter comes from the live ones

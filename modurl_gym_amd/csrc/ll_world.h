@@ -261,7 +261,7 @@ LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
 // LDS, one column per lane (element i of lane l at vc[i * stride], stride = lanes per block), the rest — rarely more
 // than a few exist — in `vc_far` (a global workspace, one column per lane of the grid): LDS is worth more to the
 // run-time-indexed per-lane records (lunar_lander.hip) than to constraints the sweeps hold in registers anyway
-// (vc_near >= 2: toi_sweeps reads vc[0], vc[stride] directly).  The position constraints are local memory.
+// (any split works: every access goes through cs_vc).  The position constraints are local memory.
 // The host test passes plain arrays with stride 1.
 struct CSolverMem { VConstraint* vc; int vc_stride; int vc_near; VConstraint* vc_far; int vc_far_stride; PConstraint* pc; int pc_stride; int cap; };
 struct CSolver {
@@ -741,12 +741,12 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     k.upperAngle[0] = k_in.upperAngle[0]; k.upperAngle[1] = k_in.upperAngle[1];
     k.motorSpeed[0] = k_in.motorSpeed[0]; k.motorSpeed[1] = k_in.motorSpeed[1];
     k.maxMotorTorque = k_in.maxMotorTorque;
-    const int n_cs = cs.count, n_vs = cs.vs;
+    const int n_cs = cs.count;
     constexpr int kReg = 4;  // constraints held in registers (the kernel runs at one wave per SIMD: 512 VGPRs per lane)
     VConstraint r0, r1, r2, r3;
     int rb0 = -1, rb1 = -1, rb2 = -1, rb3 = -1;
-    if (cs.count > 0) { r0 = cs.vc[0]; rb0 = r0.indexB; }
-    if (cs.count > 1) { r1 = cs.vc[cs.vs]; rb1 = r1.indexB; }
+    if (cs.count > 0) { r0 = cs_vc(cs, 0); rb0 = r0.indexB; }
+    if (cs.count > 1) { r1 = cs_vc(cs, 1); rb1 = r1.indexB; }
     if (cs.count > 2) { r2 = cs_vc(cs, 2); rb2 = r2.indexB; }   // (the third and fourth may live in the far workspace)
     if (cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }
     LL_DIAG_SWEEP_BEGIN(0);
@@ -782,8 +782,8 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
                       rb1 >= 0 && r1.pointCount > 1 ? r1.points[1].normalImpulse : 0.0f, rb1 >= 0 && r1.pointCount > 1 ? r1.points[1].tangentImpulse : 0.0f);
     }
     LL_DIAG_SWEEP_END(0);
-    if (rb0 >= 0) cs.vc[0] = r0;
-    if (rb1 >= 0) cs.vc[n_vs] = r1;
+    if (rb0 >= 0) cs_vc(cs, 0) = r0;
+    if (rb1 >= 0) cs_vc(cs, 1) = r1;
     if (rb2 >= 0) cs_vc(cs, 2) = r2;
     if (rb3 >= 0) cs_vc(cs, 3) = r3;
     J0_io = J0; J1_io = J1; vel_io = vel;
@@ -814,8 +814,8 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
     Vel vd = vd_io;
     VConstraint r0, r1;
     const bool h0 = cs.count > 0, h1 = cs.count > 1;
-    if (h0) r0 = cs.vc[0];
-    if (h1) r1 = cs.vc[cs.vs];
+    if (h0) r0 = cs_vc(cs, 0);
+    if (h1) r1 = cs_vc(cs, 1);
     bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
     auto state_now = [&]() {
         ToiSweepState st;

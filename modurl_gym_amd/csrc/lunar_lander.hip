@@ -228,8 +228,13 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // with all its sub-steps (toi_budget < 0, the default).  With toi_budget >= 0 (MGYM_LL_TOI_ROUNDS, profiling only) SolveTOI
 // stops after that many sub-steps and the env goes, with its unfinished state in the C_MID columns, onto L_TOI0 for
 // ll_toi_kernel.
+#ifndef LL_CONTACT_NUM_VGPR   // register budget of the contact kernel (arch VGPRs; the unified file holds twice that incl. AGPRs)
+#define LL_CONTACT_ATTR
+#else
+#define LL_CONTACT_ATTR __attribute__((amdgpu_num_vgpr(LL_CONTACT_NUM_VGPR)))
+#endif
 template <int BLK>
-__global__ void __launch_bounds__(BLK)
+__global__ void __launch_bounds__(BLK) LL_CONTACT_ATTR
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
     // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
@@ -248,8 +253,9 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
-    mem.vc_far = d.vc_far + ((uint64_t)blockIdx.x * BLK + threadIdx.x); mem.vc_far_stride = (int)(gridDim.x * BLK);
+    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNear ? d.vc_near : kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    // the two contact launches of the overlapped order run at the same time: each has its own slice of the workspace
+    mem.vc_far = (which == L_LATE ? d.vc_far_late : d.vc_far) + ((uint64_t)blockIdx.x * BLK + threadIdx.x); mem.vc_far_stride = (int)(gridDim.x * BLK);
     bool not_reset = false;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
@@ -550,6 +556,15 @@ ll_mask_scan_kernel(LLDev d, const uint8_t* __restrict__ m0, const uint8_t* __re
     }
 }
 
+// mgym_get_info: spins for `ticks` of the 100 MHz wall clock and records when it ran.  One launch per stream of a handle, issued
+// back to back: launches that sit on different hardware queues overlap in time, launches that share a queue run one after the other.
+__global__ void ll_queue_probe_kernel(unsigned long long* __restrict__ out, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < ticks) t1 = wall_clock64();
+    out[0] = t0; out[1] = t1;
+}
+
 // state blob (27 columns, identical to the CPU oracle's): raw {x,y,angle,vx,vy,w} of lander, leg0, leg1;
 // leg0_contact, leg1_contact, game_over, lander awake, prev_shaping (NaN = None), wind_idx, torque_idx,
 // step counter, episode counter.
@@ -624,6 +639,7 @@ struct LunarLanderEnv final : Env {
     int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
+    int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
@@ -674,9 +690,20 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
         dev.kd = static_cast<const LLConst*>(kdev);
-        // far velocity constraints of the 64-lane contact kernel: one column per lane of its (bounded) grid
-        MGYM_HIP(hipMalloc(&vc_far_base, (size_t)(kSolverCap - kVcNearLds) * work_grid().x * 64 * sizeof(VConstraint)));
-        dev.vc_far = static_cast<VConstraint*>(vc_far_base);
+        // far velocity constraints of the contact kernel: one column per lane of its (bounded) grid, [constraint][lane].  The main
+        // launch and the late launch of the overlapped order run concurrently, so each gets a slice of its own, sized from the
+        // grids step() really launches (MGYM_LL_VC_NEAR=0, a test knob, sends every constraint there: kSolverCap per lane).
+        vc_near_limit = getenv("MGYM_LL_VC_NEAR") ? atoi(getenv("MGYM_LL_VC_NEAR")) : kVcNearLds;
+        if (vc_near_limit < 0) vc_near_limit = 0;
+        if (vc_near_limit > kVcNearLds) vc_near_limit = kVcNearLds;
+        {
+            const size_t per_lane = (size_t)(kSolverCap - vc_near_limit);
+            const size_t lanes_main = (size_t)main_contact_grid() * gen_block, lanes_late = (size_t)late_contact_grid() * 32;
+            MGYM_HIP(hipMalloc(&vc_far_base, per_lane * (lanes_main + lanes_late) * sizeof(VConstraint)));
+            dev.vc_far = static_cast<VConstraint*>(vc_far_base);
+            dev.vc_far_late = dev.vc_far + per_lane * lanes_main;
+            dev.vc_near = vc_near_limit;
+        }
         {   // the helper stream carries the work that is NOT on the critical path: lowest priority (1 Mi envs: 3.65 -> 3.52 ms per step)
             int lo = 0, hi = 0;
             MGYM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -745,6 +772,8 @@ struct LunarLanderEnv final : Env {
         if (b > 65536) b = 65536;
         return dim3((unsigned)(b ? b : 1));
     }
+    unsigned main_contact_grid() const { return (unsigned)(((uint64_t)work_grid().x * 64 + gen_block - 1) / gen_block); }  // blocks of gen_block lanes
+    unsigned late_contact_grid() const { return work_grid().x < 256 ? work_grid().x : 256; }                               // blocks of 32 lanes
     dim3 work_grid() const {  // the worklist length is only known on the device: fixed grid, grid-stride inside
         uint64_t b = (n + kLLBlock - 1) / kLLBlock;
         if (b > 4096) b = 4096;
@@ -810,7 +839,7 @@ struct LunarLanderEnv final : Env {
             return MGYM_OK;
         }
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
-        const unsigned gb = (unsigned)(((uint64_t)work_grid().x * 64 + gen_block - 1) / gen_block);
+        const unsigned gb = main_contact_grid();
         const int first_budget = toi_rounds > 0 ? toi_first : -1;  // sub-steps the contact kernel takes itself before handing an env to ll_toi_kernel
         if (overlap) {
             // Overlapped order (see ll_classify_kernel): the contact kernel starts at once on the caller's stream; beside it,
@@ -823,7 +852,7 @@ struct LunarLanderEnv final : Env {
             launch_contact(stream, gen_block, gb, sd, io, first_budget, L_GENERAL);
             MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             launch_free(aux, sd, io);
-            launch_contact(aux, 32, work_grid().x < 256 ? work_grid().x : 256, sd, io, first_budget, L_LATE);
+            launch_contact(aux, 32, late_contact_grid(), sd, io, first_budget, L_LATE);
             MGYM_HIP(hipEventRecord(ev_join, aux));
             MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
         } else {
@@ -863,6 +892,32 @@ struct LunarLanderEnv final : Env {
     }
     int observation(const float** obs, uint64_t* col_stride) override {
         *obs = dev.obs; *col_stride = n_pad;
+        return MGYM_OK;
+    }
+    // mgym_get_info: the launch structure of this handle and whether its streams really run side by side
+    int info(std::string& out) override {
+        out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (overlap ? "overlapped" : "sequential") +
+               "\nstaged_resets=" + (staged ? "1" : "0") + "\n";
+        hipStream_t ss[3] = {stream, aux, aux2};
+        const int ns = aux2 ? 3 : 2;
+        unsigned long long* d_t = nullptr;
+        unsigned long long h_t[6] = {0, 0, 0, 0, 0, 0};
+        MGYM_HIP(hipStreamSynchronize(stream));
+        MGYM_HIP(hipStreamSynchronize(aux));
+        if (aux2) MGYM_HIP(hipStreamSynchronize(aux2));
+        MGYM_HIP(hipMalloc((void**)&d_t, sizeof h_t));
+        for (int q = 0; q < ns; ++q) hipLaunchKernelGGL(ll_queue_probe_kernel, dim3(1), dim3(1), 0, ss[q], d_t + 2 * q, 5000ull);  // 50 us each
+        for (int q = 0; q < ns; ++q) MGYM_HIP(hipStreamSynchronize(ss[q]));
+        MGYM_HIP(hipMemcpy(h_t, d_t, sizeof h_t, hipMemcpyDeviceToHost));
+        MGYM_HIP(hipFree(d_t));
+        // the largest set of probes whose intervals share an instant: count the intervals covering each start time
+        int best = 1;
+        for (int a = 0; a < ns; ++a) {
+            int c = 0;
+            for (int b = 0; b < ns; ++b) c += (h_t[2 * b] <= h_t[2 * a] && h_t[2 * a] < h_t[2 * b + 1]) ? 1 : 0;
+            if (c > best) best = c;
+        }
+        out += "streams=" + std::to_string(ns) + "\nconcurrent_streams=" + std::to_string(best) + "\n";
         return MGYM_OK;
     }
     int get_state(void* blob) override {

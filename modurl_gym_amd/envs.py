@@ -157,6 +157,13 @@ class VecEnv:
         """hipStreamSynchronize + sticky device status (raises InvalidActionError / NotResetError)."""
         _check(self._lib.mgym_sync(self._h))
 
+    def info(self):
+        """mgym_get_info as a dict: kind, n_envs, GPU_MAX_HW_QUEUES as seen at creation; LunarLander adds its launch
+        structure and how many of its streams were seen running at the same time (a probe launch on each)."""
+        buf = C.create_string_buffer(1024)
+        _check(self._lib.mgym_get_info(self._h, buf, len(buf)))
+        return dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+
     # ---- raw device-pointer path (what bench.py and a Rust/C caller use) --------------
     def reset_device(self, mask=None, obs_out=None):
         _check(self._lib.mgym_reset(self._h, _ptr(mask), _ptr(obs_out)))

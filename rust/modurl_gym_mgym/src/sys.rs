@@ -1,4 +1,4 @@
-//! Raw FFI: one declaration per symbol of include/mgym.h (ABI version 1), same order as the header.
+//! Raw FFI: one declaration per symbol of include/mgym.h (ABI version 3), same order as the header.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -7,7 +7,7 @@ pub struct mgym_env {
     _opaque: [u8; 0],
 }
 
-pub const MGYM_ABI_VERSION: c_int = 2;
+pub const MGYM_ABI_VERSION: c_int = 3;
 
 pub const MGYM_OK: c_int = 0;
 pub const MGYM_ERR_INVALID_ACTION: c_int = 1;
@@ -105,6 +105,7 @@ unsafe extern "C" {
     pub fn mgym_get_spec(kind: c_int, spec: *mut mgym_spec) -> c_int;
     pub fn mgym_sync(env: *mut mgym_env) -> c_int;
     pub fn mgym_last_error() -> *const c_char;
+    pub fn mgym_get_info(env: *mut mgym_env, buf: *mut c_char, cap: usize) -> c_int;
     pub fn mgym_malloc(device: c_int, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn mgym_free(device: c_int, ptr: *mut c_void) -> c_int;
     pub fn mgym_memcpy_h2d(device: c_int, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;

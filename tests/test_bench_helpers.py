@@ -45,6 +45,37 @@ def test_launch_mode_per_family():
     assert bench.launch_mode("graph", "lunar_lander") == "graph" and bench.launch_mode("eager", "cartpole") == "eager"
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    # `python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls N = 1; the reference is single-threaded and !Send,
+    # lunar_lander.rs:240-249, so the multi-process split is this build's): bench.py starts torch.distributed.run as a CHILD process
+    # before torch / HIP are touched; --dry-run-launch rehearses exactly that plumbing on the CPU (gloo) and prints one JSON line.
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-launch"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout          # ONE JSON line on stdout, from rank 0
+    d = json.loads(lines[0])
+    assert d["dry_run_launch"] is True and d["n_gpus"] == 2 and (d["steps"], d["warmup"]) == (3, 1)   # the same arguments reached the ranks
+    assert sorted((x["RANK"], x["LOCAL_RANK"], x["WORLD_SIZE"]) for x in d["ranks"]) == [(0, 0, 2), (1, 1, 2)]
+    # a failing child's exit code is propagated (an unknown flag makes every rank exit 2 -> torchrun fails -> non-zero)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_package_asks_for_the_hardware_queues_before_hip_initialises():
+    # LunarLander's three streams only overlap on distinct hardware queues; the package owns the knob
+    import subprocess
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import modurl_gym_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "8", r.stderr[-1000:]
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '6'; import modurl_gym_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip() == "6"            # an embedder's own setting wins
+    assert "GPU_MAX_HW_QUEUES" not in open(os.path.join(ROOT, "bench.py")).read().split("def parse")[1]   # bench.py no longer sets it itself
+
+
 def test_host_cores_follows_affinity_and_override(monkeypatch):
     n = bench.host_cores()
     assert 1 <= n <= 64 and n <= len(os.sched_getaffinity(0))

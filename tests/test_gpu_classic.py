@@ -200,6 +200,45 @@ def test_cartpole_all_branches_vs_oracle(sb, euler):
     assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
 
 
+def test_cartpole_episode_counter_wraps_at_2_pow_20_as_documented():
+    # include/mgym.h (mgym_get_state): the episode number lives in 20 bits of the counter word; an env stepped across
+    # its 1 048 576th reset draws the initial states of episodes 0, 1, ... again.  Checked against the oracle AND
+    # against a fresh handle (whose first resets ARE episodes 0, 1, ...), so the claim does not rest on the oracle's
+    # own masking.
+    n = 4096
+    env, ref, _ = both("cartpole", n, seed=77, auto_reset=True)
+    fresh = mg.VecEnv(mg.CARTPOLE, n, seed=77)
+    env.reset(), ref.reset()
+    s = ref.get_state()
+    s[6] = u32col(np.full(n, (1 << 20) - 1))   # the next reset of every env is number 2^20 - 1, the one after wraps to 0
+    ref.set_state(s), env.set_state(s)
+    assert np.array_equal(env.get_state()[6].view(np.uint32), np.full(n, (1 << 20) - 1, np.uint32))
+    big = s.copy(); big[6] = u32col(np.full(n, (5 << 20) + 123)); env.set_state(big)   # imports are reduced modulo 2^20
+    assert np.array_equal(env.get_state()[6].view(np.uint32), np.full(n, 123, np.uint32))
+    env.set_state(s)
+    rng = np.random.default_rng(5)
+    resets = np.zeros(n, np.int64)
+    first_after_wrap = np.full((4, n), np.nan, np.float32)
+    for t in range(120):
+        a = rng.integers(0, 2, n).astype(np.uint32)
+        got, exp = env.step(a), ref.step(a)
+        assert_same(got[1:], exp[1:], f"step {t} ")
+        fin = (exp[2] | exp[3]).astype(bool)
+        ref.reset(mask=fin.astype(np.uint8))
+        obs = env.observation()
+        assert np.array_equal(obs, ref.get_state()[:4]), f"step {t}: post-reset state"
+        take = fin & (resets == 1)     # second reset after the import = episode number 0 again
+        first_after_wrap[:, take] = obs[:, take]
+        resets += fin
+    assert (resets >= 2).sum() > n // 2
+    ep = env.get_state()[6].view(np.uint32)
+    assert np.array_equal(ep, ((1 << 20) - 1 + resets) % (1 << 20))
+    ep0 = fresh.reset()                # a fresh handle's first reset is episode 0 of the same (seed, env id)
+    hit = resets >= 2
+    assert np.array_equal(first_after_wrap[:, hit], ep0[:, hit])
+    fresh.close()
+
+
 def test_cartpole_large_angles_use_table_reduction():
     # stepping long after termination spins theta up: exercises reduce_fast beyond pi/4 and the
     # |x| >= 120 table reduction of mgym_math.h on the device
