@@ -1028,13 +1028,20 @@ LLD void solve_island(World& w, const PolyTab& tab, const LLConst& k, const CSol
 }
 
 // ---- b2World::SolveTOI ----------------------------------------------------------------------------------
-// Resumable: the reference's loop "evaluate the invalidated times of impact, take the earliest, sub-step that body,
-// repeat" runs `budget` sub-steps (< 0: to the end) and reports whether it finished.  Everything the loop carries
-// from one iteration to the next lives in World (sweeps incl. alpha0, per-contact toi / toiFlag / toiCount /
-// enabled, gA), so a later call with first = false continues exactly where this one stopped — the kernels use that
-// to hand the (few) environments that need sub-steps to follow-up launches over compacted lists, instead of letting
-// every lane of a wave wait for the slowest one.  Same operations in the same order either way.
-LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, bool first, int budget) {
+// The reference's loop "evaluate the invalidated times of impact, take the earliest, sub-step that body, repeat", cut
+// into the pieces of one pass so that the kernels can run the evaluations of a whole wave side by side:
+//   toi_begin     once per world.step: clear the per-step contact bits and the sweeps' alpha0
+//   toi_list      which contacts need their time of impact computed, in list order; the bodies they belong to are put
+//                 onto the common time interval (b2Sweep::Advance) — everything that ORDERS the evaluations
+//   toi_evaluate  ONE evaluation: a pure function of the body's sweep and the edge, result into the contact's TOI word
+//   toi_advance   take the minimum; advance that body, solve the TOI island, re-open that body's contacts
+// Same operations on the same operands as b2World::SolveTOI's single walk.  Everything the loop carries from one pass to
+// the next lives in World (sweeps incl. alpha0, per-contact toi / toiFlag / toiCount / enabled, gA), so it is also
+// resumable: solve_toi_part runs `budget` sub-steps (< 0: to the end) and reports whether it finished; a later call
+// with first = false continues exactly where this one stopped (follow-up launches over compacted lists, profiling only).
+struct ToiLoop { int n_order; uint32_t order_seq; };
+
+LLD bool toi_begin(World& w, ToiLoop& L, bool first) {  // false: no contacts, SolveTOI has nothing to do
     if (first) {
         for (int i = 0; i < 3; ++i) { w.b[i].islandFlag = false; w.b[i].sw.alpha0 = 0.0f; }
         bool any = false;
@@ -1046,51 +1053,70 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             ct_set_toi(w.cs, s, 1.0f);
         }
         w.gA = 0.0f;
-        if (!any) return true;
+        if (!any) return false;
     }
-    float gA = w.gA;
     // the contact list, newest first: SolveTOI only ever adds contacts (FindNewContacts after a sub-step), so the
     // order is rebuilt when the sequence counter has moved and not on every pass
+    L.n_order = contact_order(w, (uint8_t*)w.t->idx[0]);
+    L.order_seq = w.next_seq;
+    return true;
+}
+
+// b2World::SolveTOI walks the contact list once, computing the time of impact of every contact whose cached value was
+// invalidated and tracking the minimum.  Here the walk is three passes with the same per-contact order and
+// arithmetic: (1) this one lists the contacts that need a computation (w.t->idx[1][0 .. n)), (2) toi_evaluate computes
+// them, (3) toi_advance takes the minimum.
+LLD int toi_list(World& w, ToiLoop& L) {
     uint8_t* const order = (uint8_t*)w.t->idx[0];
-    int n_order = contact_order(w, order);
-    uint32_t order_seq = w.next_seq;
-    for (;;) {
+    if (w.next_seq != L.order_seq) { L.n_order = contact_order(w, order); L.order_seq = w.next_seq; }
+    uint8_t* const need = (uint8_t*)w.t->idx[1];
+    int n_need = 0;
+    for (int q = 0; q < L.n_order; ++q) {
+        const uint32_t key = ct_key(w.cs, order[q]);
+        if (!(key & CK_ENABLED) || ck_toi_count(key) > b2_maxSubSteps || (key & CK_TOIFLAG)) continue;
+        if (!w.b[ck_body(key)].awake) continue;
+        need[n_need++] = order[q];
+    }
+    // Put the sweeps onto the same time interval, in evaluation order (the shared static body carries an alpha0 too: gA).
+    // gA only ratchets up to the time of the last sub-step and every body's alpha0 is at most that, so a body is advanced
+    // at most once per pass, before its first evaluation: its sweep is final for all of them, and an evaluation depends
+    // on no other body — which is what lets the evaluations of a pass run in any order, or side by side.
+    float gA = w.gA;
+    for (int j = 0; j < n_need; ++j) {
+        Body& bB = w.b[ck_body(ct_key(w.cs, need[j]))];
+        if (gA < bB.sw.alpha0) gA = bB.sw.alpha0;
+        else if (bB.sw.alpha0 < gA) sweep_advance(bB.sw, gA);
+    }
+    w.gA = gA;
+    return n_need;
+}
+
+// (`wo` may be ANOTHER lane's World record, in LDS: the contact kernel deals the evaluations of a wave out over all its lanes)
+LLD void toi_evaluate(World& wo, const PolyTab& tab, int slot) {
+    const uint32_t key = ct_key(wo.cs, slot);
+    const int body = ck_body(key);
+    const Body& bB = wo.b[body];
+    const float alpha0 = bB.sw.alpha0;  // == gA after toi_list
+    V2 ev[2];
+    edge_verts(wo, ck_edge(key), ev[0], ev[1]);
+    float beta;
+    LL_STAMP(8);
+    int state = (LL_WHATIF(wo, WI_NO_TOI_EVAL) || (LL_WHATIF(wo, WI_SUB_NO_REEVAL) && wo.gA > 0.0f)) ? TOI_SEPARATED : time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
+    LL_STAMP(9);
+    float alpha;
+    if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+    else alpha = 1.0f;
+    ct_set_toi(wo.cs, slot, alpha);
+    ct_set_key(wo.cs, slot, key | CK_TOIFLAG);
+}
+
+enum { TOI_DONE = 0, TOI_AGAIN = 1, TOI_OUT_OF_BUDGET = 2 };
+LLD int toi_advance(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, ToiLoop& L, int& budget) {
+    uint8_t* const order = (uint8_t*)w.t->idx[0];
+    const int n_order = L.n_order;
+    {
         int minSlot = -1;
         float minAlpha = 1.0f;
-        if (w.next_seq != order_seq) { n_order = contact_order(w, order); order_seq = w.next_seq; }
-        // b2World::SolveTOI walks the contact list once, computing the time of impact of every contact whose cached
-        // value was invalidated and tracking the minimum.  Here the walk is split into three passes with the same
-        // per-contact order and arithmetic: (1) list the contacts that need a computation, (2) compute them —
-        // lanes of a wave need different list positions, and one pass over the compacted list runs
-        // time_of_impact max-over-lanes(own count) times instead of once per list position — (3) take the minimum.
-        uint8_t* const need = (uint8_t*)w.t->idx[1];
-        int n_need = 0;
-        for (int q = 0; q < n_order; ++q) {
-            const uint32_t key = ct_key(w.cs, order[q]);
-            if (!(key & CK_ENABLED) || ck_toi_count(key) > b2_maxSubSteps || (key & CK_TOIFLAG)) continue;
-            if (!w.b[ck_body(key)].awake) continue;
-            need[n_need++] = order[q];
-        }
-        for (int j = 0; j < n_need; ++j) {
-            const uint32_t key = ct_key(w.cs, need[j]);
-            const int body = ck_body(key);
-            Body& bB = w.b[body];
-            // put the sweeps onto the same time interval (the shared static body carries an alpha0 too)
-            float alpha0 = gA;
-            if (gA < bB.sw.alpha0) { alpha0 = bB.sw.alpha0; gA = alpha0; }
-            else if (bB.sw.alpha0 < gA) { alpha0 = gA; sweep_advance(bB.sw, alpha0); }
-            V2 ev[2];
-            edge_verts(w, ck_edge(key), ev[0], ev[1]);
-            float beta;
-            LL_STAMP(8);
-            int state = (LL_WHATIF(w, WI_NO_TOI_EVAL) || (LL_WHATIF(w, WI_SUB_NO_REEVAL) && gA > 0.0f)) ? TOI_SEPARATED : time_of_impact(ev, tab, poly_of(body), bB.sw, beta);
-            LL_STAMP(9);
-            float alpha;
-            if (state == TOI_TOUCHING) alpha = fmin2(alpha0 + (1.0f - alpha0) * beta, 1.0f);
-            else alpha = 1.0f;
-            ct_set_toi(w.cs, need[j], alpha);
-            ct_set_key(w.cs, need[j], key | CK_TOIFLAG);
-        }
         for (int q = 0; q < n_order; ++q) {
             const uint32_t key = ct_key(w.cs, order[q]);
             if (!(key & CK_ENABLED)) continue;
@@ -1100,8 +1126,8 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             if (alpha < minAlpha) { minSlot = order[q]; minAlpha = alpha; }
         }
         LL_STAMP(16);
-        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha || LL_WHATIF(w, WI_NO_SUBSTEPS)) { w.gA = gA; return true; }
-        if (budget == 0) { w.gA = gA; return false; }  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
+        if (minSlot < 0 || 1.0f - 10.0f * b2_epsilon < minAlpha || LL_WHATIF(w, WI_NO_SUBSTEPS)) return TOI_DONE;
+        if (budget == 0) return TOI_OUT_OF_BUDGET;  // the evaluated times of impact are cached in the contacts: the next call picks the same minimum
         if (budget > 0) --budget;
 
         Contact& minContact = *(Contact*)&w.t->tmp;
@@ -1109,8 +1135,8 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         const int dyn = minContact.body;
         Body& bB = w.b[dyn];
         Sweep backup = bB.sw;
-        const float gA_backup = gA;
-        gA = minAlpha;  // bA->Advance(minAlpha) on the ground
+        const float gA_backup = w.gA;
+        w.gA = minAlpha;  // bA->Advance(minAlpha) on the ground
         body_advance(bB, minAlpha);
         contact_update(w, tab, minContact);
         minContact.toiFlag = false;
@@ -1119,9 +1145,9 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
             minContact.enabled = false;
             ct_put(w.cs, minSlot, minContact);
             bB.sw = backup;
-            gA = gA_backup;
+            w.gA = gA_backup;
             body_sync_transform(bB);
-            continue;
+            return TOI_AGAIN;
         }
         body_set_awake(bB, true);
         LL_STAMP(17);
@@ -1186,7 +1212,20 @@ LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CS
         }
         if (!LL_WHATIF(w, WI_SUB_NO_FIND)) find_new_contacts(w, moved, nm);
         LL_STAMP(18);
-        if (LL_WHATIF(w, WI_ONE_SUBSTEP)) { w.gA = gA; return true; }
+        if (LL_WHATIF(w, WI_ONE_SUBSTEP)) return TOI_DONE;
+    }
+    return TOI_AGAIN;
+}
+
+// one lane runs every piece itself (host check, the kernels that do not deal evaluations out)
+LLD bool solve_toi_part(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, bool first, int budget) {
+    ToiLoop L;
+    if (!toi_begin(w, L, first)) return true;
+    for (;;) {
+        const int n_need = toi_list(w, L);
+        for (int j = 0; j < n_need; ++j) toi_evaluate(w, tab, ((const uint8_t*)w.t->idx[1])[j]);
+        const int r = toi_advance(w, tab, k, mem, dt, L, budget);
+        if (r != TOI_AGAIN) return r == TOI_DONE;
     }
 }
 

@@ -233,8 +233,11 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 #else
 #define LL_CONTACT_ATTR __attribute__((amdgpu_num_vgpr(LL_CONTACT_NUM_VGPR)))
 #endif
+// threads per block of the contact kernel: a block is ONE wave.  With the World records in LDS (BLK <= 32) BLK of its lanes
+// carry an environment each; the other lanes of the wave exist only to take their share of the time-of-impact evaluations.
+constexpr int ll_contact_threads(int blk) { return blk <= 32 ? 64 : blk; }
 template <int BLK>
-__global__ void __launch_bounds__(BLK) LL_CONTACT_ATTR
+__global__ void __launch_bounds__(ll_contact_threads(BLK)) LL_CONTACT_ATTR
 ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
     // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
@@ -243,19 +246,23 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
     // 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
     constexpr bool kWorldLds = BLK <= 32;
+    constexpr int kThreads = ll_contact_threads(BLK);
     constexpr int kVcNear = kVcNearLds;
     __shared__ World s_world[kWorldLds ? BLK : 1];
     LL_TMP_DECL(BLK);
     __shared__ PolyTab tab;
     __shared__ VConstraint s_vc[kVcNear * BLK];
     __shared__ uint32_t s_hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
-    const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)BLK, BLK > 32 ? 0u : 1u};  // 64-lane blocks: KEY and SEQ only
+    __shared__ uint16_t s_task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
+    const bool env_lane = threadIdx.x < BLK;
+    const int own = env_lane ? (int)threadIdx.x : 0;             // per-lane records exist for the env lanes only
+    const CtHot hot{(LL_LDS uint32_t*)s_hot + own, (uint32_t)BLK, BLK > 32 ? 0u : 1u};  // 64-lane blocks: KEY and SEQ only
     stage_tab(tab, LLK(d));
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[threadIdx.x]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNear ? d.vc_near : kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc = &s_vc[own]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNear ? d.vc_near : kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     // the two contact launches of the overlapped order run at the same time: each has its own slice of the workspace
-    mem.vc_far = (which == L_LATE ? d.vc_far_late : d.vc_far) + ((uint64_t)blockIdx.x * BLK + threadIdx.x); mem.vc_far_stride = (int)(gridDim.x * BLK);
+    mem.vc_far = (which == L_LATE ? d.vc_far_late : d.vc_far) + ((uint64_t)blockIdx.x * BLK + own); mem.vc_far_stride = (int)(gridDim.x * BLK);
     bool not_reset = false;
     uint32_t overflow = 0u;
     uint32_t finished = 0;
@@ -269,9 +276,15 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     const uint64_t total = c0_up + c1;
     for (uint64_t q0 = (uint64_t)blockIdx.x * BLK; q0 < total; q0 += (uint64_t)gridDim.x * BLK) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
-        const bool have = q < c0 || (q >= c0_up && q < total);
+        const bool have = env_lane && (q < c0 || (q >= c0_up && q < total));
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
+        bool stepping = false;      // this lane is inside world.step
+        bool step_complete = true;  // ... and has finished it (false only with toi_budget >= 0: profiling)
+        World w_local;
+        World& w = kWorldLds ? s_world[kWorldLds ? own : 0] : w_local;
+        EnvRegs e;
+        uint32_t action = 0u;
         if (have) {
             if (spread) {
                 const uint64_t h0 = q * c1 / total, h1 = (q + 1) * c1 / total;
@@ -279,10 +292,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
             } else {
                 i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
             }
-            World w_local;
-            World& w = kWorldLds ? s_world[kWorldLds ? threadIdx.x : 0] : w_local;
-            w.t = LL_TMP_PTR();
-            EnvRegs e;
+            w.t = (LL_LDS WorldTmp*)s_tmp + own;
             ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
@@ -290,22 +300,59 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                 if (io.done_out) io.done_out[i] = 0;
                 if (io.trunc_out) io.trunc_out[i] = 0;
             } else {
-                const uint32_t action = io.act[i];
-                float d0, d1;
+                action = io.act[i];
+                float d0, d1, m_power, s_power;
                 ll_dispersion(d, i, e, d0, d1);
-                if (ll_step_begin(w, e, tab, LLK(d), mem, action, d0, d1, toi_budget)) {
-                    float state[8], reward; uint32_t done;
-                    ll_step_finish(w, e, action, state, reward, done);
-                    ll_store(d, i, w, e);
-                    ll_emit(d, io, i, state, reward, done);
-                    is_done = done != 0u;
-                    to_reset = d.auto_reset && done;
-                } else {
-                    ll_store(d, i, w, e, true);
-                    to_toi = true;
-                }
-                overflow |= w.overflow;
+                ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
+                world_step_begin(w, tab, LLK(d), mem);                                                     // world.step up to SolveTOI, :1066
+                stepping = true;
             }
+        }
+        // b2World::SolveTOI.  With the World records in LDS the wave runs its passes in lock step and DEALS THE
+        // TIME-OF-IMPACT EVALUATIONS OF A PASS OUT OVER ALL 64 LANES: an evaluation (GJK + root finder: the longest
+        // dependent chain of the step, ~25 k cycles) is a pure function of the body's sweep and the edge, both in the
+        // owner's LDS record, and its result goes into the owner's staged TOI word — so any lane can do it.  A lane's own
+        // list is 1-9 evaluations long while most lanes of the wave hold none: one lane per evaluation turns the wave's
+        // ~18 sequential evaluation slots per step into ~6 (the arithmetic of each evaluation is unchanged).
+        if constexpr (kWorldLds) {
+            if (toi_budget < 0) {
+                ToiLoop L;
+                bool running = stepping && toi_begin(w, L, true);
+                int budget = -1;
+                while (__any(running)) {   // wave-uniform
+                    const int n_need = running ? toi_list(w, L) : 0;
+                    int incl = n_need;     // inclusive prefix sum over the wave: where this lane's evaluations go in the task table
+                    for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
+                    const int n_tasks = __shfl(incl, 63);
+                    const int offs = incl - n_need;
+                    for (int j = 0; j < n_need; ++j) s_task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)s_tmp + own)->idx[1][j]);
+                    __syncthreads();
+                    for (int t = (int)threadIdx.x; t < n_tasks; t += kThreads) {
+                        const uint32_t task = s_task[t];
+                        toi_evaluate(s_world[task >> 4], tab, (int)(task & 15u));
+                    }
+                    __syncthreads();
+                    if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
+                }
+            } else if (stepping) {
+                step_complete = solve_toi_part(w, tab, LLK(d), mem, kStepDt, true, toi_budget);
+            }
+        } else {
+            if (stepping) step_complete = solve_toi_part(w, tab, LLK(d), mem, kStepDt, true, toi_budget);
+        }
+        if (stepping) {
+            if (step_complete) {
+                float state[8], reward; uint32_t done;
+                ll_step_finish(w, e, action, state, reward, done);
+                ll_store(d, i, w, e);
+                ll_emit(d, io, i, state, reward, done);
+                is_done = done != 0u;
+                to_reset = d.auto_reset && done;
+            } else {
+                ll_store(d, i, w, e, true);
+                to_toi = true;
+            }
+            overflow |= w.overflow;
         }
         ll_push(d, L_TOI0, to_toi, (uint32_t)i);
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
@@ -822,12 +869,12 @@ struct LunarLanderEnv final : Env {
     }
     void launch_contact(hipStream_t s, int block, unsigned gb, const LLDev& d, const LLIo& io, int toi_budget, int which) {
         switch (block) {
-        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(8), 0, s, d, io, toi_budget, which); break;
-        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(16), 0, s, d, io, toi_budget, which); break;
-        case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(40), 0, s, d, io, toi_budget, which); break;
-        case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(48), 0, s, d, io, toi_budget, which); break;
-        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(64), 0, s, d, io, toi_budget, which); break;
-        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(32), 0, s, d, io, toi_budget, which); break;
+        case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(ll_contact_threads(8)), 0, s, d, io, toi_budget, which); break;
+        case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(ll_contact_threads(16)), 0, s, d, io, toi_budget, which); break;
+        case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(ll_contact_threads(40)), 0, s, d, io, toi_budget, which); break;
+        case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(ll_contact_threads(48)), 0, s, d, io, toi_budget, which); break;
+        case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(ll_contact_threads(64)), 0, s, d, io, toi_budget, which); break;
+        default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(ll_contact_threads(32)), 0, s, d, io, toi_budget, which); break;
         }
     }
     int step(const void* actions, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
