@@ -37,7 +37,10 @@ enum Col : int {
 enum Flag : uint32_t {
     F_AWAKE0 = 1u << 0, F_GAME_OVER = 1u << 3, F_LEG0 = 1u << 4, F_LEG1 = 1u << 5, F_HAS_WORLD = 1u << 6,
     F_DETERMINISTIC = 1u << 7, F_NEW_CONTACTS = 1u << 8, F_PENDING0 = 1u << 9, F_STEPPED = 1u << 12,
-    F_PREV_SOME = 1u << 13, F_TOUCHING = 1u << 14 /* some cached contact is touching (worklist bucketing) */, F_NCONTACT_SHIFT = 16
+    F_PREV_SOME = 1u << 13, F_TOUCHING = 1u << 14 /* some cached contact is touching (worklist bucketing) */,
+    F_RESUME = 1u << 15 /* only between two kernels of one step: the free-flight kernel has done the island solve, the contact kernel continues at
+                           FindNewContacts (ll_free_store_resume); bits 9-11 then say which proxies moved, C_MID holds the sweeps' start */,
+    F_NCONTACT_SHIFT = 16
 };
 
 struct LLDev {
@@ -63,6 +66,8 @@ struct LLDev {
     const uint32_t* episode_src;  // staged resets: this LLDev addresses the SHADOW columns; the episode counter comes from the live ones
     int prep;            // staged resets: ll_reset_kernel lists the envs it has reset (L_PREP), their next reset is then prepared
     uint8_t* env_class;  // overlapped launch order: class byte per env for this step (ll_classify_kernel)
+    int fused_tail;  // fused order of step(): lists and counters are maintained by ll_epilogue_kernel (lunar_lander.hip)
+    int resume;  // the free-flight kernel stores the post-solve state of an env it has to hand over (F_RESUME); the contact kernel continues from it
     int split;   // 0: sequential launch order; 1: overlapped (contact list built by ll_classify_kernel; the free-flight kernel lists only what it declines)
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;  // tools/ll_whatif.hip only
@@ -86,8 +91,10 @@ struct EnvRegs {  // LunarLanderV3 fields beside the world (lunar_lander.rs:232-
 #define LLK(d) (*(d).kd)
 
 // mid = true: continue an unfinished SolveTOI (the env was stored by ll_store(..., mid = true) earlier in this step)
-__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e, CtHot hot, bool mid = false) {
+__device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, EnvRegs& e, CtHot hot, bool mid_in = false) {
     const uint32_t flags = ST(C_FLAGS);
+    const bool mid = mid_in || (flags & F_RESUME);   // a resumed env carries its sweeps' start in the C_MID columns too
+    w.resume = flags & F_RESUME;
     for (int b = 0; b < 3; ++b) {
         Body& bd = w.b[b];
         const int c = C_BODY + 9 * b;
@@ -281,6 +288,16 @@ __device__ __forceinline__ void ll_post_step(const Body& lander, bool game_over,
     if (game_over || fabsf(state[0]) >= 1.0f) { done = 1u; reward = -100.0f; }
     else if (!lander.awake) { done = 1u; reward = 100.0f; }
     e.step += 1u;
+}
+
+// The step of an env the free-flight kernel stopped after the island solve (F_RESUME, ll_free.h): b2Island::Solve's last act —
+// FindNewContacts over the proxies that moved, in body-list order — then on with SolveTOI as for everyone else.
+__device__ __forceinline__ void ll_resume_after_island(World& w) {
+    int moved[3], nm = 0;
+    for (int b = 2; b >= 0; --b)
+        if (w.pending & (1u << b)) moved[nm++] = b;
+    find_new_contacts(w, moved, nm);
+    w.pending = 0; w.resume = false;
 }
 
 // step(), lunar_lander.rs:919-1167, in resumable pieces (disp = the two raw U(-1,1) draws of :973-974):

@@ -6,8 +6,9 @@
 // This file restates exactly that reduced step with every quantity in VGPRs (no contact cache, no local
 // arrays), using the SAME primitives as the general path (rj_*, integrate_*, sleep_update, fixture_sync),
 // in the same order, so results are bit-identical to world_step().  It never creates a contact: if the
-// updated fat AABBs start to overlap a ground edge (or any other precondition fails) it reports `false`
-// and the caller hands the untouched environment to the general kernel through the worklist.
+// updated fat AABBs start to overlap a ground edge it stops after the island solve and the contact kernel resumes the
+// environment from there (FREE_RESUME); if a precondition fails at the start it reports FREE_DECLINED and the caller hands the
+// untouched environment to the general path through the worklist.
 #pragma once
 #include "ll_env.h"
 
@@ -126,15 +127,50 @@ __device__ __forceinline__ bool ll_free_move_proxy(AABB& tree, AABB aabb, V2 dis
     return true;
 }
 
-// One full Gym::step of a contact-free environment.  Returns false (nothing may be stored) when the env
-// must go through the general path instead.
-__device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
-                                                 float disp0, float disp1, float state[8], float& reward, uint32_t& done) {
+// An env whose step ends with a contact being CREATED (its new fat AABB overlaps a ground edge's) has done everything
+// b2World::Step does before FindNewContacts exactly as the general path would have — the same primitives in the same
+// order — so its post-solve state is stored (bodies, joints, fat AABBs, the sweeps' start in the C_MID columns, which
+// proxies moved in the pending bits, F_RESUME) and the contact kernel RESUMES it there: FindNewContacts, SolveTOI, the tail
+// of the step (ll_resume_after_island, ll_env.h) instead of redoing the 180-sweep island solve from the old state.
+__device__ __forceinline__ void ll_free_store_resume(const LLDev& d, uint64_t i, const FreeRegs& f, const EnvRegs& e, uint32_t moved) {
+    uint32_t flags = f.flags & (F_GAME_OVER | F_LEG0 | F_LEG1 | F_HAS_WORLD | F_DETERMINISTIC | F_STEPPED | F_PREV_SOME);
+    for (int b = 0; b < 3; ++b) {
+        const Body& bd = f.b[b];
+        const int c = C_BODY + 9 * b;
+        ST(c + 0) = as_u32(bd.xf.p.x); ST(c + 1) = as_u32(bd.xf.p.y);
+        ST(c + 2) = as_u32(bd.sw.c.x); ST(c + 3) = as_u32(bd.sw.c.y);
+        ST(c + 4) = as_u32(bd.sw.a);
+        ST(c + 5) = as_u32(bd.v.x); ST(c + 6) = as_u32(bd.v.y);
+        ST(c + 7) = as_u32(bd.w);
+        ST(c + 8) = as_u32(bd.sleepTime);
+        if (bd.awake) flags |= 1u << b;
+        ST(C_FAT + 4 * b + 0) = as_u32(f.fat[b].lo.x); ST(C_FAT + 4 * b + 1) = as_u32(f.fat[b].lo.y);
+        ST(C_FAT + 4 * b + 2) = as_u32(f.fat[b].hi.x); ST(C_FAT + 4 * b + 3) = as_u32(f.fat[b].hi.y);
+        ST(C_MID + 4 * b + 0) = as_u32(bd.sw.c0.x); ST(C_MID + 4 * b + 1) = as_u32(bd.sw.c0.y);   // SolveTOI sweeps from here
+        ST(C_MID + 4 * b + 2) = as_u32(bd.sw.a0); ST(C_MID + 4 * b + 3) = as_u32(0.0f);
+    }
+    ST(C_MID + 12) = as_u32(0.0f);
+    for (int j = 0; j < 2; ++j) {
+        const int c = C_JOINT + 5 * j;
+        ST(c + 0) = as_u32(f.jt[j].impulse.x); ST(c + 1) = as_u32(f.jt[j].impulse.y);
+        ST(c + 2) = as_u32(f.jt[j].motorImpulse); ST(c + 3) = as_u32(f.jt[j].lowerImpulse); ST(c + 4) = as_u32(f.jt[j].upperImpulse);
+    }
+    ST(C_FLAGS) = flags | F_RESUME | ((moved & 7u) << 9);   // no cached contacts yet (count 0), newContacts = false
+    ST(C_WIND) = (uint32_t)e.wind_idx; ST(C_TORQUE) = (uint32_t)e.torque_idx;   // advanced by the wind of this step (:927-959)
+}
+
+// One full Gym::step of a contact-free environment.  FREE_DONE: stepped.  FREE_DECLINED: nothing may be stored, the env
+// must go through the general path from its old state.  FREE_RESUME: the island solve is done and a contact has to be
+// created: store with ll_free_store_resume(moved) and hand the env to the contact kernel.
+enum { FREE_DECLINED = 0, FREE_DONE = 1, FREE_RESUME = 2 };
+__device__ __forceinline__ int ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
+                                                 float disp0, float disp1, float state[8], float& reward, uint32_t& done, uint32_t& moved) {
     const LLConst& k = LLK(d);
+    moved = 0u;
     if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
         for (int b = 0; b < 3; ++b)
             if ((f.flags >> 9) & (1u << b))
-                if (ll_any_ground_overlap(d, i, f.fat[b])) return false;
+                if (ll_any_ground_overlap(d, i, f.fat[b])) return FREE_DECLINED;
     }
     float m_power, s_power;
     ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, m_power, s_power);
@@ -178,6 +214,7 @@ __device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, Fre
         for (int b = 0; b < 3; ++b) body_set_awake(f.b[b], false);
 
     // b2Body::SynchronizeFixtures in body-list order (leg1, leg0, lander), then FindNewContacts
+    bool create = false;
     for (int b = 2; b >= 0; --b) {
         Body& bd = f.b[b];
         Xf xf1 = bd.xf;
@@ -190,12 +227,15 @@ __device__ __forceinline__ bool ll_free_env_step(const LLDev& d, uint64_t i, Fre
         aabb.lo = mk(fmin2(a1.lo.x, a2.lo.x), fmin2(a1.lo.y, a2.lo.y));
         aabb.hi = mk(fmax2(a1.hi.x, a2.hi.x), fmax2(a1.hi.y, a2.hi.y));
         V2 c1 = 0.5f * (a1.lo + a1.hi), c2 = 0.5f * (a2.lo + a2.hi);
-        if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1))
-            if (ll_any_ground_overlap(d, i, f.fat[b])) return false;  // a contact would be created: general path
+        if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1)) {
+            moved |= 1u << b;
+            if (ll_any_ground_overlap(d, i, f.fat[b])) create = true;  // a contact would be created: the contact kernel takes over from here
+        }
     }
+    if (create) return FREE_RESUME;
     // SolveTOI: no contacts.  ClearForces; inv_dt0 = inv_dt.
     ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, m_power, s_power, state, reward, done);
-    return true;
+    return FREE_DONE;
 }
 
 }  // namespace mgym

@@ -34,6 +34,9 @@ enum : uint32_t { WI_NO_COLLIDE_UPDATE = 1u, WI_NO_TOI_EVAL = 2u, WI_NO_SUBSTEPS
 #ifndef LL_TOI_SWEEP_STAT
 #define LL_TOI_SWEEP_STAT(count, done)  // host statistics builds count the sweeps a sub-step really ran
 #endif
+#ifndef LL_POS_ITER_STAT
+#define LL_POS_ITER_STAT(kind, count, iters, solved)  // ... and the position iterations (kind 0: island, 1: sub-step)
+#endif
 
 namespace mgym {
 namespace ll {
@@ -65,6 +68,7 @@ struct World {
     float gA;               // b2World::SolveTOI: alpha0 of the static ground's sweep (its c0/a0 never move; only alpha0 ratchets)
     uint32_t pending;       // bits 0..2: proxy of body i waits in the move buffer (test seam only)
     bool newContacts, stepped_once;
+    bool resume;            // the free-flight kernel has done this step's island solve; continue at FindNewContacts (ll_env.h F_RESUME)
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
     bool terrain_dirty;       // smooth[] was regenerated (reset): store it back
@@ -892,8 +896,12 @@ LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1,
             okA = rj_solve_position(J0, 0, k, pos.b0, pos.b1);
             okB = rj_solve_position(J1, 1, k, pos.b0, pos.b2);
         }
-        if (contactsOkay && okA && okB) { solved = true; break; }
-        if (pos_same(before.b0, pos.b0) && pos_same(before.b1, pos.b1) && pos_same(before.b2, pos.b2)) break;
+#ifdef LL_POS_ITER_TRACE
+        LL_POS_ITER_TRACE(it, pos);
+#endif
+        if (contactsOkay && okA && okB) { solved = true; LL_POS_ITER_STAT(0, n_cs, it + 1, 1); break; }
+        if (pos_same(before.b0, pos.b0) && pos_same(before.b1, pos.b1) && pos_same(before.b2, pos.b2)) { LL_POS_ITER_STAT(0, n_cs, it + 1, 2); break; }
+        if (it == 59) LL_POS_ITER_STAT(0, n_cs, 60, 0);
     }
     pos_io = pos;
     return solved;

@@ -68,8 +68,9 @@ constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kW
 //   L_PREP       staged resets: envs that have just been reset and whose NEXT reset is to be prepared (+ L_PREP_SLOW: declined by the fast path)
 //   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
 constexpr int kToiRounds = 4;
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, L_COUNT = L_TOI0 + kToiRounds,
-       L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed at the start of every call)
+//   C_NEXT       (a counter only) the length of the NEXT step's L_GENERAL while ll_epilogue_kernel is filling it; C_TICKET: its block ticket
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_TICKET,
+       L_COUNT, L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed by rebuild_list() / at the start of every call of the unfused order)
 
 struct LLIo {
     const uint32_t* act;
@@ -113,7 +114,8 @@ __device__ __forceinline__ void ll_push_back(const LLDev& d, int which_list, int
 // block-aggregated append for kernels whose every wave appends (ll_classify_kernel): ONE atomic per block and list — thousands
 // of per-wave atomics on one counter serialise at ~11 ns each.  All threads of the block must call it (it synchronises);
 // `s_cnt` is block-shared scratch for (blockDim.x / 64 + 1) words.
-__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt) {
+__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt, int which_count = -1) {
+    if (which_count < 0) which_count = which;   // (the epilogue fills next step's L_GENERAL under the counter C_NEXT)
     const unsigned long long mask = __ballot(want);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     __syncthreads();  // s_cnt may still be read by the previous call
@@ -122,7 +124,7 @@ __device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool wa
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < nw; ++w) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-        s_cnt[nw] = tot ? atomicAdd(d.work_count + which, tot) : 0u;
+        s_cnt[nw] = tot ? atomicAdd(d.work_count + which_count, tot) : 0u;
     }
     __syncthreads();
     if (want) d.work_list[(uint64_t)which * d.n_pad + s_cnt[nw] + s_cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
@@ -187,9 +189,10 @@ ll_free_kernel(LLDev d, LLIo io) {
             } else {
                 FreeRegs f; EnvRegs e;
                 ll_free_load(d, i, f, e);
-                float state[8], reward, d0, d1; uint32_t done;
+                float state[8], reward, d0, d1; uint32_t done, moved;
                 ll_dispersion(d, i, e, d0, d1);
-                if (ll_free_env_step(d, i, f, e, tab, io.act[i], d0, d1, state, reward, done)) {
+                const int how = ll_free_env_step(d, i, f, e, tab, io.act[i], d0, d1, state, reward, done, moved);
+                if (how == FREE_DONE) {
                     ll_free_store(d, i, f, e);
                     if (io.rew) io.rew[i] = reward;
                     if (io.done_out) io.done_out[i] = (uint8_t)done;
@@ -197,7 +200,11 @@ ll_free_kernel(LLDev d, LLIo io) {
                     ll_write_obs(d, io, i, state);
                     to_reset = d.auto_reset && done;
                     is_done = done != 0u;
+                    if (to_reset) d.env_class[i] = 2;   // finished: a fresh scene by the end of this call (ll_epilogue_kernel goes by this, not by the flag word)
                 } else {
+                    // a contact is being created at the end of the step: the contact kernel finishes it, from the post-solve
+                    // state (FREE_RESUME) or, if a pending proxy already overlapped the ground at the start, from the old one
+                    if (how == FREE_RESUME && d.resume) ll_free_store_resume(d, i, f, e, moved);
                     to_general = true;
                 }
             }
@@ -268,6 +275,11 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     uint32_t finished = 0;
     const uint32_t* list = d.work_list + (uint64_t)which * d.n_pad;  // L_GENERAL (two-ended) or L_LATE
     const uint64_t c0 = d.work_count[which], c1 = which == L_GENERAL ? d.work_count[L_GENERAL_T] : 0u;
+    if (d.fused_tail && which == L_GENERAL && blockIdx.x == 0 && threadIdx.x == 0) {
+        // fused order: the lists the LAST launches of the previous step consumed (its direct resets, behind the epilogue) are
+        // cleared by the first kernel of this one; everything else is cleared by the epilogue's last block
+        d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u;
+    }
     // bucket 1: the touching bucket starts at a block boundary (waves of one kind); bucket 2: the touching envs — the ones
     // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
     // of the first q entries floor(q * c1 / total) come from the touching list
@@ -301,10 +313,14 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                 if (io.trunc_out) io.trunc_out[i] = 0;
             } else {
                 action = io.act[i];
-                float d0, d1, m_power, s_power;
-                ll_dispersion(d, i, e, d0, d1);
-                ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
-                world_step_begin(w, tab, LLK(d), mem);                                                     // world.step up to SolveTOI, :1066
+                if (w.resume) {   // the free-flight kernel has taken this step up to the end of the island solve (ll_free.h)
+                    ll_resume_after_island(w);
+                } else {
+                    float d0, d1, m_power, s_power;
+                    ll_dispersion(d, i, e, d0, d1);
+                    ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
+                    world_step_begin(w, tab, LLK(d), mem);                                                     // world.step up to SolveTOI, :1066
+                }
                 stepping = true;
             }
         }
@@ -348,6 +364,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                 ll_emit(d, io, i, state, reward, done);
                 is_done = done != 0u;
                 to_reset = d.auto_reset && done;
+                if (to_reset) d.env_class[i] = 2;   // (see ll_free_kernel)
             } else {
                 ll_store(d, i, w, e, true);
                 to_toi = true;
@@ -533,7 +550,8 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
             f.b[0].force = force; f.b[0].torque = torque;
             float state[8], reward, d0, d1; uint32_t done;
             ll_dispersion(d, i, e, d0, d1);
-            if (ll_free_env_step(d, i, f, e, tab, 0u, d0, d1, state, reward, done)) {
+            uint32_t moved;
+            if (ll_free_env_step(d, i, f, e, tab, 0u, d0, d1, state, reward, done, moved) == FREE_DONE) {
                 e.episode += 1u;
                 ll_free_store(d, i, f, e);
                 ll_write_obs(d, io, i, state);
@@ -587,6 +605,81 @@ ll_apply_copy_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* 
             const float o = shadow_obs[(uint64_t)k * d.n_pad + i];
             d.obs[(uint64_t)k * d.n_pad + i] = o;
             if (io.obs_out) io.obs_out[(uint64_t)k * d.n + i] = o;
+        }
+    }
+}
+
+// The END of a step in the fused order, one launch instead of counter memsets + classify (next step) + select + copy:
+//  (1) staged resets: every finished env (L_RESET) whose prepared next episode fits gets it copied in (and goes onto L_PREP: its
+//      NEXT reset is prepared afterwards), the others go onto L_RESET_DIRECT for the reset kernel behind this one;
+//  (2) the contact list and class byte of the NEXT step, from the flag words the step kernels have just stored.  A finished
+//      env (class byte 2, written by the kernel that finished it) is a fresh scene by the end of this call — copied in above by
+//      another block, or reset by the launch behind — and is classed as free flight without looking at its flag word;
+//  (3) the last block to finish publishes the new list's length and clears the counters this step has consumed.
+__global__ void __launch_bounds__(1024)
+ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __restrict__ shadow_obs, LLIo io, int staged) {
+    __shared__ uint32_t s_cnt[17];
+    __shared__ uint32_t s_ent[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    if (staged) {
+        const uint32_t* list = d.work_list + (uint64_t)L_RESET * d.n_pad;
+        const uint32_t total = d.work_count[L_RESET];
+        const uint32_t per = (total + gridDim.x - 1) / gridDim.x;          // a contiguous share of the list per block
+        const uint32_t lo = blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+        for (uint32_t base = lo; base < hi; base += blockDim.x) {          // block-uniform
+            const uint32_t idx = base + tid;
+            const bool valid = idx < hi;
+            uint32_t i = 0u;
+            bool fits = false;
+            if (valid) {
+                i = list[idx];
+                fits = shadow[(uint64_t)C_EPISODE * d.n_pad + i] == ST(C_EPISODE) + 1u;
+            }
+            ll_push_block(d, L_PREP, fits, i, s_cnt);
+            ll_push_block(d, L_RESET_DIRECT, valid && !fits, i, s_cnt);
+            s_ent[tid] = fits ? i : 0xffffffffu;
+            __syncthreads();
+            const uint32_t n_here = hi - base < blockDim.x ? hi - base : blockDim.x;
+            for (uint32_t k = wave; k < n_here; k += nw) {                 // one wave per env: its columns lie n_pad words apart
+                const uint64_t i = s_ent[k];
+                if (i == 0xffffffffu) continue;
+                for (int t = lane; t < C_CONTACT + kSlots + 8; t += 64) {
+                    if (t < C_CONTACT) ST(t) = shadow[(uint64_t)t * d.n_pad + i];
+                    else if (t < C_CONTACT + kSlots) ST(C_CONTACT + 16 * (t - C_CONTACT)) = 0u;  // a fresh world has no contacts
+                    else {
+                        const int k8 = t - C_CONTACT - kSlots;
+                        const float o = shadow_obs[(uint64_t)k8 * d.n_pad + i];
+                        d.obs[(uint64_t)k8 * d.n_pad + i] = o;
+                        if (io.obs_out) io.obs_out[(uint64_t)k8 * d.n + i] = o;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // block-uniform trip count
+        const uint64_t i = base + tid;
+        bool to_general = false;
+        if (i < d.n) {
+            if (d.env_class[i] != 2) {
+                const uint32_t flags = ST(C_FLAGS);
+                to_general = (flags & F_HAS_WORLD) && !ll_free_eligible(flags);
+            }
+            d.env_class[i] = to_general ? 1 : 0;
+        }
+        ll_push_block(d, L_GENERAL, to_general, (uint32_t)i, s_cnt, C_NEXT);
+    }
+    // (No device-scope fence: the list ENTRIES are only read by later kernels, and the counts travel by atomics that this thread has
+    // already waited for.  A __threadfence() here costs 90 us per launch — every wave writes back its XCD's L2.)
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t ticket = atomicAdd(d.work_count + C_TICKET, 1u);
+        if (ticket == gridDim.x - 1) {   // every other block has added its count (its thread 0 waited for that atomic before taking a ticket)
+            d.work_count[L_GENERAL] = atomicExch(d.work_count + C_NEXT, 0u);
+            d.work_count[L_GENERAL_T] = 0u; d.work_count[L_LATE] = 0u; d.work_count[L_RESET] = 0u;
+            if (!staged) { d.work_count[L_RESET_SLOW] = 0u; d.work_count[L_RESET_DIRECT] = 0u; }
+            d.work_count[C_TICKET] = 0u;
         }
     }
 }
@@ -666,7 +759,8 @@ struct LunarLanderEnv final : Env {
     void* shadow_base = nullptr;        // staged resets: shadow state columns [C_COUNT][n_pad] and observation [8][n_pad]
     void* shadow_obs = nullptr;
     hipStream_t aux2 = nullptr;         // ... prepared on this stream (its own: behind the free-flight kernel on `aux` it costs 0.1 ms per step)
-    hipEvent_t ev_prep = nullptr, ev_prepared = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_prepared = nullptr, ev_free_done = nullptr;
+    bool prep_due = false;              // a preparation has been marked (mark_prepare) and not launched yet
     bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
     int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
     uint8_t* env_class = nullptr;       // [n] class of each env for this step (ll_classify_kernel): 0 free flight, 1 contact path
@@ -685,6 +779,8 @@ struct LunarLanderEnv final : Env {
     int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : 0;       // 1: touching / non-touching envs at opposite ends of the worklist
     int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
+    int fused_tail = getenv("MGYM_LL_FUSED_TAIL") ? atoi(getenv("MGYM_LL_FUSED_TAIL")) : 1;  // 1 (default): the fused order of step() (ll_epilogue_kernel); needs the overlapped order and none of the profiling knobs
+    int resume = getenv("MGYM_LL_RESUME") ? atoi(getenv("MGYM_LL_RESUME")) : 1;  // 1 (default): envs the free-flight kernel stops at a new contact are resumed after their island solve (0: redone from the old state)
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
 
@@ -701,6 +797,7 @@ struct LunarLanderEnv final : Env {
         if (shadow_obs) (void)hipFree(shadow_obs);
         if (ev_prep) (void)hipEventDestroy(ev_prep);
         if (ev_prepared) (void)hipEventDestroy(ev_prepared);
+        if (ev_free_done) (void)hipEventDestroy(ev_free_done);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
     }
@@ -733,6 +830,9 @@ struct LunarLanderEnv final : Env {
         dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err; dev.done_count = d_done;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
         dev.bucket = bucket;
+        dev.resume = resume && !general_only;
+        fused_tail = fused_tail && overlap && !general_only && toi_rounds == 0 && bucket == 0;
+        dev.fused_tail = fused_tail;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
         MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
@@ -777,6 +877,7 @@ struct LunarLanderEnv final : Env {
             MGYM_HIP(hipStreamCreateWithPriority(&aux2, hipStreamNonBlocking, lo));
             MGYM_HIP(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
             MGYM_HIP(hipEventCreateWithFlags(&ev_prepared, hipEventDisableTiming));
+            MGYM_HIP(hipEventCreateWithFlags(&ev_free_done, hipEventDisableTiming));
         }
         return MGYM_OK;
     }
@@ -793,17 +894,28 @@ struct LunarLanderEnv final : Env {
     }
     // `stream` waits for the preparation work put on aux2 so far: before anything appends to L_PREP or reads the shadow columns
     int join_helpers() override {
+        if (prep_due) { int st = launch_prepare(false, true, false); if (st != MGYM_OK) return st; }   // marked by the last step, no step followed
         if (prep_pending) { MGYM_HIP(hipStreamWaitEvent(stream, ev_prepared, 0)); prep_pending = false; }
         return MGYM_OK;
     }
-    // prepare the next reset of the envs on L_PREP (or of every env), after what `stream` holds so far
-    int launch_prepare(bool all) {
+    // prepare the next reset of the envs on L_PREP (or of every env), after what `stream` holds so far.
+    // Fused order: the preparation that follows a step is only MARKED here (event recorded) and launched by the next step()
+    // behind its free-flight kernel (after_free) — started at once it competes with the contact kernel for the SIMDs at the very
+    // moment that kernel's one-wave-per-SIMD blocks are being placed (contact kernel 1.04 -> 1.15 ms, itself 0.11 -> 0.7 ms).
+    int mark_prepare() {
+        MGYM_HIP(hipEventRecord(ev_prep, stream));
+        prep_due = true;
+        return MGYM_OK;
+    }
+    int launch_prepare(bool all, bool deferred = false, bool after_free = false) {
         LLDev sh = dev;
         sh.st = static_cast<uint32_t*>(shadow_base); sh.obs = static_cast<float*>(shadow_obs);
         sh.episode_src = dev.st; sh.prep = 0; sh.split = 0;
         const LLIo none{nullptr, nullptr, nullptr, nullptr, nullptr};
-        MGYM_HIP(hipEventRecord(ev_prep, stream));
+        if (!deferred) MGYM_HIP(hipEventRecord(ev_prep, stream));
+        prep_due = false;
         MGYM_HIP(hipStreamWaitEvent(aux2, ev_prep, 0));
+        if (after_free) MGYM_HIP(hipStreamWaitEvent(aux2, ev_free_done, 0));
         if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, aux2, sh, none, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)L_PREP_SLOW);
         else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, aux2, sh, none, list_ptr(L_PREP), (const uint32_t*)dev.work_count + L_PREP, (int)L_PREP_SLOW);
         // (an env the fast path declines — it never does for a fresh scene — keeps a shadow episode that does not fit and
@@ -828,6 +940,15 @@ struct LunarLanderEnv final : Env {
     }
 
     const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
+    unsigned classify_grid() const { return (unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256); }
+    // The fused order keeps the contact list and class bytes of the NEXT step valid at all times: ll_epilogue_kernel builds them
+    // at the end of every step, and whatever else changes the state (reset, set_state, reset_deterministic) rebuilds them here.
+    int rebuild_list() {
+        LLDev sd = dev; sd.split = 1;
+        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(ll_classify_kernel, dim3(classify_grid()), dim3(1024), 0, stream, sd);
+        return MGYM_OK;
+    }
     // resets of the envs on the L_RESET list (or of every env): fast path, then the (normally empty) declined list
     void launch_resets(const LLIo& io, bool all, int from_list = L_RESET, bool prep = false) {
         LLDev d = dev;
@@ -850,6 +971,7 @@ struct LunarLanderEnv final : Env {
             launch_resets(io, all, L_RESET, stage);
             if (stage) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
         }
+        if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
@@ -857,6 +979,7 @@ struct LunarLanderEnv final : Env {
         if (n == 0) return MGYM_OK;
         LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 2);
+        if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
@@ -885,8 +1008,41 @@ struct LunarLanderEnv final : Env {
             MGYM_HIP(hipGetLastError());
             return MGYM_OK;
         }
-        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
         const unsigned gb = main_contact_grid();
+        if (fused_tail) {
+            // Fused order (the default): this step's contact list and class bytes were built by the previous call's last kernel, so
+            // the contact kernel starts at once; beside it, on the helper stream, the free-flight kernel and the short contact launch
+            // for the envs it hands over; after the join ONE epilogue launch: prepared resets copied in, next step's list, counters.
+            LLDev sd = dev; sd.split = 1;
+            MGYM_HIP(hipEventRecord(ev_fork, stream));
+            launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
+            MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            launch_free(aux, sd, io);
+            const bool stage = dev.auto_reset && staging_now();
+            if (stage && prep_due) {   // the preparation the previous step marked: behind the free-flight kernel, beside the late contact launch
+                MGYM_HIP(hipEventRecord(ev_free_done, aux));
+                int st = launch_prepare(false, true, true);
+                if (st != MGYM_OK) return st;
+            }
+            launch_contact(aux, 32, late_contact_grid(), sd, io, -1, L_LATE);
+            MGYM_HIP(hipEventRecord(ev_join, aux));
+            MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+            LLIo rio{nullptr, obs_out, nullptr, nullptr, nullptr};
+            if (stage) {
+                int st = join_helpers();
+                if (st != MGYM_OK) return st;
+                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1);
+                launch_resets(rio, false, L_RESET_DIRECT, true);   // normally empty
+                st = mark_prepare();
+                if (st != MGYM_OK) return st;
+            } else {
+                if (dev.auto_reset) launch_resets(rio, false);
+                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)nullptr, (const float*)nullptr, rio, 0);
+            }
+            MGYM_HIP(hipGetLastError());
+            return MGYM_OK;
+        }
+        MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
         const int first_budget = toi_rounds > 0 ? toi_first : -1;  // sub-steps the contact kernel takes itself before handing an env to ll_toi_kernel
         if (overlap) {
             // Overlapped order (see ll_classify_kernel): the contact kernel starts at once on the caller's stream; beside it,
@@ -894,7 +1050,7 @@ struct LunarLanderEnv final : Env {
             // envs it declined (a contact was created at the end of their step).  Stream-ordered for the caller and
             // capturable (fork / join by events).  262 144 envs: 1.82 -> 1.52 ms per step (table in init()).
             LLDev sd = dev; sd.split = 1;
-            hipLaunchKernelGGL(ll_classify_kernel, dim3((unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256)), dim3(1024), 0, stream, sd);
+            hipLaunchKernelGGL(ll_classify_kernel, dim3(classify_grid()), dim3(1024), 0, stream, sd);
             MGYM_HIP(hipEventRecord(ev_fork, stream));
             launch_contact(stream, gen_block, gb, sd, io, first_budget, L_GENERAL);
             MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
@@ -976,6 +1132,7 @@ struct LunarLanderEnv final : Env {
     int set_state(const void* blob) override {
         if (n == 0) return MGYM_OK;
         hipLaunchKernelGGL(ll_import_kernel, dim3((unsigned)((n + kLLBlock - 1) / kLLBlock)), dim3(kLLBlock), 0, stream, dev, static_cast<const uint32_t*>(blob));
+        if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

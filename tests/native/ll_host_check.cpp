@@ -13,7 +13,14 @@
 #ifdef LL_HOST_STATS  // -DLL_HOST_STATS: histogram of the sub-step velocity sweeps actually run, by constraint count (tools/ll_work_stats.sh)
 static unsigned long g_toi_sweeps[13][181], g_rounds_by_touch[2][6], g_rounds_by_ncont[9][6];
 #define LL_TOI_SWEEP_STAT(count, done) do { g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++; if ((done) == 180 && g_trace_left > 0) { --g_trace_left; printf("-- a sub-step that ran all 180 sweeps (%d constraints); state words after sweeps 1..180 (v.x v.y w n00 t00 n01 t01 n10 t10 n11 t11):\n", (int)(count)); for (int q_ = 0; q_ < 180; ++q_) if (q_ < 6 || q_ % 20 == 0 || q_ >= 174) { printf("   %3d:", q_ + 1); for (int z_ = 0; z_ < 11; ++z_) printf(" %08x", g_trace[q_][z_]); printf("\n"); } } } while (0)
-static unsigned g_trace[181][11]; static int g_trace_left = 6;
+static unsigned g_trace[181][11]; static int g_trace_left = 0;
+static unsigned long g_pos_iters[2][13][61], g_pos_how[2][3];
+static unsigned g_ptrace[60][9]; static unsigned long g_pcycle_at[62], g_pcycle_period[62]; static int g_ptrace_print = 3;
+#define LL_POS_ITER_TRACE(it, pos) do { const float z_[9] = {(pos).b0.c.x, (pos).b0.c.y, (pos).b0.a, (pos).b1.c.x, (pos).b1.c.y, (pos).b1.a, (pos).b2.c.x, (pos).b2.c.y, (pos).b2.a}; memcpy(g_ptrace[(it)], z_, sizeof z_); } while (0)
+#define LL_POS_ITER_STAT(kind, count, iters, solved) do { if ((kind) == 0 && (solved) == 0) { int at_ = 61, per_ = 0; for (int j_ = 1; j_ < 60 && at_ == 61; ++j_) for (int i_ = j_ - 1; i_ >= 0; --i_) if (!memcmp(g_ptrace[j_], g_ptrace[i_], 36)) { at_ = j_; per_ = j_ - i_; break; } g_pcycle_at[at_]++; g_pcycle_period[per_]++; \
+    if (at_ == 61 && g_ptrace_print > 0) { --g_ptrace_print; printf("-- island position solve that ran out without repeating (%d contacts):\n", (int)(count)); for (int q_ = 0; q_ < 60; q_ += (q_ < 4 || q_ >= 54) ? 1 : 10) { printf("   %2d:", q_); for (int z_ = 0; z_ < 9; ++z_) printf(" %08x", g_ptrace[q_][z_]); printf("\n"); } } } \
+    g_pos_iters[kind][(count) < 12 ? (count) : 12][(iters)]++; g_pos_how[kind][(solved)]++; } while (0)
+#define LL_POS_ITER_STAT_OLD(kind, count, iters, solved) do { g_pos_iters[kind][(count) < 12 ? (count) : 12][(iters)]++; g_pos_how[kind][(solved)]++; } while (0)
 #define LL_TOI_SWEEP_TRACE(done, cur, count) do { for (int z_ = 0; z_ < 11; ++z_) g_trace[(done) - 1][z_] = (cur).w[z_]; } while (0)
 #endif
 #include "../../modurl_gym_amd/csrc/ll_free.h"
@@ -55,7 +62,7 @@ int main(int argc, char** argv) {
     uint32_t h_hot[3 * kSlots]; const CtHot hot{h_hot, 1u, toi_staged};  // the staged KEY / SEQ / TOI words (LDS on the GPU)
     VConstraint h_vc0[kSlots]; PConstraint h_pc0[kSlots];
     CSolverMem mem0; mem0.vc = h_vc0; mem0.vc_stride = 1; mem0.vc_near = kSlots; mem0.vc_far = nullptr; mem0.vc_far_stride = 0; mem0.pc = h_pc0; mem0.pc_stride = 1; mem0.cap = kSlots;
-    unsigned long fast_steps = 0, general_steps = 0;
+    unsigned long fast_steps = 0, general_steps = 0, resumed_steps = 0;
     int max_slots = 0, max_rounds = 0; unsigned long hist[kSlots + 1] = {0}, round_hist[8] = {0};
     unsigned long mism = 0, exact = 0, total = 0, done_total = 0, overflow = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -85,7 +92,10 @@ int main(int argc, char** argv) {
                 FreeRegs f; EnvRegs e;
                 ll_free_load(d, i, f, e);
                 ll_dispersion(d, i, e, d0, d1);
-                if (ll_free_env_step(d, i, f, e, tab, act[i], d0, d1, state, reward, done)) { ll_free_store(d, i, f, e); fast = true; fast_steps++; }
+                uint32_t moved;
+                const int how = ll_free_env_step(d, i, f, e, tab, act[i], d0, d1, state, reward, done, moved);
+                if (how == FREE_DONE) { ll_free_store(d, i, f, e); fast = true; fast_steps++; }
+                else if (how == FREE_RESUME && (i & 1u) == 0u) { ll_free_store_resume(d, i, f, e, moved); resumed_steps++; }   // as ll_free_kernel does (every other env: both hand-over forms are checked)
             }
             if (!fast) {
                 // same structure as ll_general_kernel + the ll_toi_kernel rounds: world.step up to its first
@@ -99,7 +109,9 @@ int main(int argc, char** argv) {
 #endif
                 ll_load(d, i, w, e, hot);
                 ll_dispersion(d, i, e, d0, d1);
-                bool fin = ll_step_begin(w, e, tab, d.k, mem, act[i], d0, d1, 0);
+                bool fin;
+                if (w.resume) { ll_resume_after_island(w); fin = solve_toi_part(w, tab, d.k, mem, kStepDt, true, 0); }   // as ll_contact_kernel does
+                else fin = ll_step_begin(w, e, tab, d.k, mem, act[i], d0, d1, 0);
                 int rounds = 0;
                 while (!fin) {
                     ll_store(d, i, w, e, true);
@@ -139,7 +151,7 @@ int main(int argc, char** argv) {
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
-    printf("fast-path steps %lu, general-path steps %lu\n", fast_steps, general_steps);
+    printf("fast-path steps %lu, general-path steps %lu (of which resumed after the free path's island solve: %lu)\n", fast_steps, general_steps, resumed_steps);
     printf("max simultaneous cached contacts %d; histogram:", max_slots);
     for (int q = 0; q <= kSlots; ++q) printf(" %lu", hist[q]);
     printf("\n");
@@ -156,6 +168,15 @@ int main(int argc, char** argv) {
         for (int q = 0; q <= 180; ++q) { tot += g_toi_sweeps[c][q]; sum += g_toi_sweeps[c][q] * q; if (q == 180) full += g_toi_sweeps[c][q]; if (q <= 16) le16 += g_toi_sweeps[c][q]; if (q <= 48) le48 += g_toi_sweeps[c][q]; }
         if (tot) printf("sub-step velocity solves with %d constraints: %lu; sweeps run: mean %.1f, <=16: %.1f%%, <=48: %.1f%%, all 180: %.1f%%\n", c, tot, (double)sum / tot, 100.0 * le16 / tot, 100.0 * le48 / tot, 100.0 * full / tot);
     }
+#endif
+#ifdef LL_HOST_STATS
+    for (int c = 0; c < 13; ++c) {
+        unsigned long tot = 0, sum = 0, full = 0, le4 = 0, le16 = 0;
+        for (int q = 0; q <= 60; ++q) { tot += g_pos_iters[0][c][q]; sum += g_pos_iters[0][c][q] * q; if (q == 60) full += g_pos_iters[0][c][q]; if (q <= 4) le4 += g_pos_iters[0][c][q]; if (q <= 16) le16 += g_pos_iters[0][c][q]; }
+        if (tot) printf("island position solves with %d contact constraints: %lu; iterations: mean %.1f, <=4: %.1f%%, <=16: %.1f%%, all 60: %.1f%%\n", c, tot, (double)sum / tot, 100.0 * le4 / tot, 100.0 * le16 / tot, 100.0 * full / tot);
+    }
+    printf("island position solves that ran out: first repeated state at iteration (61 = never):"); for (int q = 0; q < 62; ++q) if (g_pcycle_at[q]) printf(" %d:%lu", q, g_pcycle_at[q]); printf("\n   period:"); for (int q = 0; q < 62; ++q) if (g_pcycle_period[q]) printf(" %d:%lu", q, g_pcycle_period[q]); printf("\n");
+    printf("island position solves ended: solved %lu, fixed point (unsolved) %lu, ran out %lu\n", g_pos_how[0][1], g_pos_how[0][2], g_pos_how[0][0]);
 #endif
     ora_vec_free(ov);
     return mism ? 1 : 0;
