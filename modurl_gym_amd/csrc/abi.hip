@@ -317,6 +317,11 @@ int mgym_sync(mgym_env* env) {
                        "not solved; that environment's results are undefined until it is reset)");
         return MGYM_ERR_CAPACITY;
     }
+    if (bits & DEV_ERR_INTERNAL) {
+        set_last_error("LunarLander: internal error — a finished environment had no fitting prepared reset while the engine believed every one had "
+                       "(staged resets, lunar_lander.hip direct_possible); that environment was not reset.  Please report; MGYM_LL_STAGED_RESET=0 avoids the path");
+        return MGYM_ERR_HIP;
+    }
     if (bits & DEV_ERR_NOT_RESET) {
         set_last_error("You forgot to call reset()");
         return MGYM_ERR_NOT_RESET;

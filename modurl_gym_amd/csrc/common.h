@@ -30,7 +30,7 @@ inline int grid_for(uint64_t work_items) {
 }
 
 // device-side sticky status bits (OR-ed into Env::d_err)
-enum : uint32_t { DEV_ERR_INVALID_ACTION = 1u, DEV_ERR_NOT_RESET = 2u, DEV_ERR_CONTACT_OVERFLOW = 4u, DEV_ERR_SOLVER_OVERFLOW = 8u };
+enum : uint32_t { DEV_ERR_INVALID_ACTION = 1u, DEV_ERR_NOT_RESET = 2u, DEV_ERR_CONTACT_OVERFLOW = 4u, DEV_ERR_SOLVER_OVERFLOW = 8u, DEV_ERR_INTERNAL = 16u };
 
 // Base of every environment family: one device, one stream, engine-owned SoA state.
 struct Env {

@@ -617,7 +617,7 @@ ll_apply_copy_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* 
 //      another block, or reset by the launch behind — and is classed as free flight without looking at its flag word;
 //  (3) the last block to finish publishes the new list's length and clears the counters this step has consumed.
 __global__ void __launch_bounds__(1024)
-ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __restrict__ shadow_obs, LLIo io, int staged) {
+ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __restrict__ shadow_obs, LLIo io, int staged, int direct_launch_follows) {
     __shared__ uint32_t s_cnt[17];
     __shared__ uint32_t s_ent[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
@@ -637,6 +637,9 @@ ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __
             }
             ll_push_block(d, L_PREP, fits, i, s_cnt);
             ll_push_block(d, L_RESET_DIRECT, valid && !fits, i, s_cnt);
+            // the host only launches the direct resets while something it knows of may have invalidated prepared states (see
+            // LunarLanderEnv::direct_possible); a misfit it did not expect would leave the env unreset: reported, never silent
+            if (valid && !fits && !direct_launch_follows) atomicOr(d.err, DEV_ERR_INTERNAL);
             s_ent[tid] = fits ? i : 0xffffffffu;
             __syncthreads();
             const uint32_t n_here = hi - base < blockDim.x ? hi - base : blockDim.x;
@@ -760,6 +763,12 @@ struct LunarLanderEnv final : Env {
     void* shadow_obs = nullptr;
     hipStream_t aux2 = nullptr;         // ... prepared on this stream (its own: behind the free-flight kernel on `aux` it costs 0.1 ms per step)
     hipEvent_t ev_prep = nullptr, ev_prepared = nullptr, ev_free_done = nullptr;
+    // Staged resets: every env has a fitting prepared episode (shadow episode == live + 1) from the moment a staged reset of ALL envs
+    // has prepared them, and keeps one (each copy-in queues the next preparation; a fresh scene spawns far above the highest terrain, so
+    // preparing it on the free-flight path cannot fail) UNLESS something else moves an episode counter or resets without preparing:
+    // mgym_set_state, a dispersion override, a masked or unstaged reset, steps captured into a graph (they reset directly).  Only then
+    // can a finished env need the direct path, and only then does step() launch its two (normally empty) kernels behind the epilogue.
+    bool direct_possible = true;
     bool prep_due = false;              // a preparation has been marked (mark_prepare) and not launched yet
     bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
     int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
@@ -970,6 +979,8 @@ struct LunarLanderEnv final : Env {
             if (!all) hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
             launch_resets(io, all, L_RESET, stage);
             if (stage) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
+            if (stage && all) direct_possible = false;   // every env has a fitting prepared successor from here on
+            else if (!stage) direct_possible = true;     // (a masked staged reset prepares the envs it resets and says nothing about the others: unchanged)
         }
         if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
@@ -978,6 +989,7 @@ struct LunarLanderEnv final : Env {
     int reset_deterministic(float* obs_out) override {
         if (n == 0) return MGYM_OK;
         LLIo io{nullptr, obs_out, nullptr, nullptr, nullptr};
+        direct_possible = true;
         hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 2);
         if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
@@ -1031,13 +1043,14 @@ struct LunarLanderEnv final : Env {
             if (stage) {
                 int st = join_helpers();
                 if (st != MGYM_OK) return st;
-                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1);
-                launch_resets(rio, false, L_RESET_DIRECT, true);   // normally empty
+                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1, direct_possible ? 1 : 0);
+                if (direct_possible) launch_resets(rio, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
                 st = mark_prepare();
                 if (st != MGYM_OK) return st;
             } else {
                 if (dev.auto_reset) launch_resets(rio, false);
-                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)nullptr, (const float*)nullptr, rio, 0);
+                if (dev.auto_reset && staged) direct_possible = true;   // resets computed here leave no prepared successor behind
+                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)nullptr, (const float*)nullptr, rio, 0, 1);
             }
             MGYM_HIP(hipGetLastError());
             return MGYM_OK;
@@ -1131,12 +1144,14 @@ struct LunarLanderEnv final : Env {
     }
     int set_state(const void* blob) override {
         if (n == 0) return MGYM_OK;
+        direct_possible = true;   // imported episode counters need not match the prepared ones
         hipLaunchKernelGGL(ll_import_kernel, dim3((unsigned)((n + kLLBlock - 1) / kLLBlock)), dim3(kLLBlock), 0, stream, dev, static_cast<const uint32_t*>(blob));
         if (fused_tail) { int st = rebuild_list(); if (st != MGYM_OK) return st; }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
     int set_dispersion(const float* disp) override {
+        direct_possible = true;
         if (staged) {  // states prepared under the other dispersion source no longer fit: episode 0 never equals a live counter + 1
             int st = join_helpers();
             if (st != MGYM_OK) return st;
