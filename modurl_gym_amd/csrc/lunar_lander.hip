@@ -69,7 +69,7 @@ constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kW
 //   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
 constexpr int kToiRounds = 4;
 //   C_NEXT       (a counter only) the length of the NEXT step's L_GENERAL while ll_epilogue_kernel is filling it; C_TICKET: its block ticket
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_TICKET,
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_TICKET, C_TICKET2,
        L_COUNT, L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed by rebuild_list() / at the start of every call of the unfused order)
 
 struct LLIo {
@@ -163,6 +163,49 @@ ll_classify_kernel(LLDev d) {
 // register-only fast path (ll_free.h).  Sequential order: everything else — and every env the fast path declines —
 // goes onto L_GENERAL for the contact kernel behind it.  Overlapped order (d.split): the contact class is being stepped
 // by the contact kernel beside this one; only the declined envs are listed (L_LATE).  Finished envs go onto L_RESET.
+// ll_free_pass: one pass of a wave over the 64 envs from `base`; returns whether this lane's env has to go down the contact path.
+__device__ __forceinline__ bool ll_free_pass(const LLDev& d, const LLIo& io, const PolyTab& tab, uint64_t base, bool& not_reset, uint32_t& finished) {
+    const uint64_t i = base + threadIdx.x;
+    // overlapped order: envs of the contact class are being stepped (or were, already) by the contact kernel beside us
+    const bool valid = i < d.n && !(d.split && d.env_class[i]);
+    bool to_general = false, to_reset = false, is_done = false;
+    if (valid) {
+        const uint32_t flags = ST(C_FLAGS);
+        if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+            not_reset = true;
+            if (io.rew) io.rew[i] = 0.0f;
+            if (io.done_out) io.done_out[i] = 0;
+            if (io.trunc_out) io.trunc_out[i] = 0;
+        } else if (!ll_free_eligible(flags)) {
+            to_general = true;
+        } else {
+            FreeRegs f; EnvRegs e;
+            ll_free_load(d, i, f, e);
+            float state[8], reward, d0, d1; uint32_t done, moved;
+            ll_dispersion(d, i, e, d0, d1);
+            const int how = ll_free_env_step(d, i, f, e, tab, io.act[i], d0, d1, state, reward, done, moved);
+            if (how == FREE_DONE) {
+                ll_free_store(d, i, f, e);
+                if (io.rew) io.rew[i] = reward;
+                if (io.done_out) io.done_out[i] = (uint8_t)done;
+                if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
+                ll_write_obs(d, io, i, state);
+                to_reset = d.auto_reset && done;
+                is_done = done != 0u;
+                if (to_reset) d.env_class[i] = 2;   // finished: a fresh scene by the end of this call (ll_epilogue_kernel goes by this, not by the flag word)
+            } else {
+                // a contact is being created at the end of the step: the contact path finishes it, from the post-solve
+                // state (FREE_RESUME) or, if a pending proxy already overlapped the ground at the start, from the old one
+                if (how == FREE_RESUME && d.resume) ll_free_store_resume(d, i, f, e, moved);
+                to_general = true;
+            }
+        }
+    }
+    ll_push(d, L_RESET, to_reset, (uint32_t)i);
+    finished += (uint32_t)__popcll(__ballot(is_done));
+    return to_general;
+}
+
 template <int OCC>
 __global__ void __launch_bounds__(kLLBlock, OCC)
 ll_free_kernel(LLDev d, LLIo io) {
@@ -173,50 +216,14 @@ ll_free_kernel(LLDev d, LLIo io) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // wave-uniform trip count
         const uint64_t i = base + threadIdx.x;
-        // overlapped order: envs of the contact class are being stepped (or were, already) by the contact kernel beside us
-        const bool valid = i < d.n && !(d.split && d.env_class[i]);
-        bool to_general = false, to_reset = false, is_done = false, touching = false;
-        if (valid) {
-            const uint32_t flags = ST(C_FLAGS);
-            touching = d.bucket && (flags & F_TOUCHING);
-            if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
-                not_reset = true;
-                if (io.rew) io.rew[i] = 0.0f;
-                if (io.done_out) io.done_out[i] = 0;
-                if (io.trunc_out) io.trunc_out[i] = 0;
-            } else if (!ll_free_eligible(flags)) {
-                to_general = true;
-            } else {
-                FreeRegs f; EnvRegs e;
-                ll_free_load(d, i, f, e);
-                float state[8], reward, d0, d1; uint32_t done, moved;
-                ll_dispersion(d, i, e, d0, d1);
-                const int how = ll_free_env_step(d, i, f, e, tab, io.act[i], d0, d1, state, reward, done, moved);
-                if (how == FREE_DONE) {
-                    ll_free_store(d, i, f, e);
-                    if (io.rew) io.rew[i] = reward;
-                    if (io.done_out) io.done_out[i] = (uint8_t)done;
-                    if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
-                    ll_write_obs(d, io, i, state);
-                    to_reset = d.auto_reset && done;
-                    is_done = done != 0u;
-                    if (to_reset) d.env_class[i] = 2;   // finished: a fresh scene by the end of this call (ll_epilogue_kernel goes by this, not by the flag word)
-                } else {
-                    // a contact is being created at the end of the step: the contact kernel finishes it, from the post-solve
-                    // state (FREE_RESUME) or, if a pending proxy already overlapped the ground at the start, from the old one
-                    if (how == FREE_RESUME && d.resume) ll_free_store_resume(d, i, f, e, moved);
-                    to_general = true;
-                }
-            }
-        }
+        const bool to_general = ll_free_pass(d, io, tab, base, not_reset, finished);
         if (d.split) {
             ll_push(d, L_LATE, to_general, (uint32_t)i);  // declined by the fast path: a short contact launch of its own
         } else {
+            const bool touching = to_general && d.bucket && (ST(C_FLAGS) & F_TOUCHING);
             ll_push(d, L_GENERAL, to_general && !touching, (uint32_t)i);
             ll_push_back(d, L_GENERAL, L_GENERAL_T, to_general && touching, (uint32_t)i);
         }
-        ll_push(d, L_RESET, to_reset, (uint32_t)i);
-        finished += (uint32_t)__popcll(__ballot(is_done));
     }
     ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
@@ -243,68 +250,70 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // threads per block of the contact kernel: a block is ONE wave.  With the World records in LDS (BLK <= 32) BLK of its lanes
 // carry an environment each; the other lanes of the wave exist only to take their share of the time-of-impact evaluations.
 constexpr int ll_contact_threads(int blk) { return blk <= 32 ? 64 : blk; }
+
+// The LDS of a block that runs the contact path:
+// velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
+// Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
+// being updated, collide_edge_polygon's polygon buffer, the slot lists: 720 B per lane, all indexed at run time) in LDS
+// instead of scratch: ~100 cycles per dependent access instead of >= 500 (1.45 -> 1.29 ms per step at 262 144 envs,
+// scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
+// 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
 template <int BLK>
-__global__ void __launch_bounds__(ll_contact_threads(BLK)) LL_CONTACT_ATTR
-ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
-    // velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
-    // Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
-    // being updated, collide_edge_polygon's polygon buffer, the slot lists: 720 B per lane, all indexed at run time) in LDS
-    // instead of scratch: ~100 cycles per dependent access instead of >= 500 (1.45 -> 1.29 ms per step at 262 144 envs,
-    // scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
-    // 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
+struct ContactLds {
+    static constexpr bool kWorldLds = BLK <= 32;
+    World world[kWorldLds ? BLK : 1];
+    WorldTmp tmp[BLK];
+    PolyTab tab;
+    VConstraint vc[kVcNearLds * BLK];
+    uint32_t hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
+    uint16_t task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
+    uint32_t late[64];                             // single-launch step: envs this wave's free-flight pass hands to its own contact path
+};
+
+// where a wave of the contact path takes its environments from: entry q of a list that is filled from both ends
+// (c0 entries from the front — rounded up to c0_up slots —, c1 from the back, `back` = index of the last slot)
+struct ContactList { const uint32_t* list; uint64_t back, c0, c0_up, c1; bool spread; };
+LLD uint64_t ll_list_entry(const ContactList& L, uint64_t q, uint64_t total) {
+    if (L.spread) {
+        const uint64_t h0 = q * L.c1 / total, h1 = (q + 1) * L.c1 / total;
+        return h1 > h0 ? L.list[L.back - h0] : L.list[q - h0];
+    }
+    return q < L.c0 ? L.list[q] : L.list[L.back - (q - L.c0_up)];
+}
+
+// The contact path over a compacted list: wind / engines, then b2World::Step — Collide, the 180-sweep island solve, position
+// iterations, new contacts, SolveTOI with all its sub-steps (toi_budget < 0, the default).  With toi_budget >= 0
+// (MGYM_LL_TOI_ROUNDS, profiling only) SolveTOI stops after that many sub-steps and the env goes, with its unfinished state in the
+// C_MID columns, onto L_TOI0 for ll_toi_kernel.  The wave takes entries q_first + lane, q_first + q_stride + lane, ...
+// (S.tab must have been staged.)
+template <int BLK>
+__device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, int toi_budget, const ContactList& CL, uint64_t q_first, uint64_t q_stride,
+                                                VConstraint* far_lane0, int far_stride, ContactLds<BLK>& S, bool& not_reset, uint32_t& overflow, uint32_t& finished) {
     constexpr bool kWorldLds = BLK <= 32;
     constexpr int kThreads = ll_contact_threads(BLK);
-    constexpr int kVcNear = kVcNearLds;
-    __shared__ World s_world[kWorldLds ? BLK : 1];
-    LL_TMP_DECL(BLK);
-    __shared__ PolyTab tab;
-    __shared__ VConstraint s_vc[kVcNear * BLK];
-    __shared__ uint32_t s_hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
-    __shared__ uint16_t s_task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
+    const PolyTab& tab = S.tab;
     const bool env_lane = threadIdx.x < BLK;
     const int own = env_lane ? (int)threadIdx.x : 0;             // per-lane records exist for the env lanes only
-    const CtHot hot{(LL_LDS uint32_t*)s_hot + own, (uint32_t)BLK, BLK > 32 ? 0u : 1u};  // 64-lane blocks: KEY and SEQ only
-    stage_tab(tab, LLK(d));
+    const CtHot hot{(LL_LDS uint32_t*)S.hot + own, (uint32_t)BLK, BLK > 32 ? 0u : 1u};  // 64-lane blocks: KEY and SEQ only
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
-    mem.vc = &s_vc[own]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNear ? d.vc_near : kVcNear; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
-    // the two contact launches of the overlapped order run at the same time: each has its own slice of the workspace
-    mem.vc_far = (which == L_LATE ? d.vc_far_late : d.vc_far) + ((uint64_t)blockIdx.x * BLK + own); mem.vc_far_stride = (int)(gridDim.x * BLK);
-    bool not_reset = false;
-    uint32_t overflow = 0u;
-    uint32_t finished = 0;
-    const uint32_t* list = d.work_list + (uint64_t)which * d.n_pad;  // L_GENERAL (two-ended) or L_LATE
-    const uint64_t c0 = d.work_count[which], c1 = which == L_GENERAL ? d.work_count[L_GENERAL_T] : 0u;
-    if (d.fused_tail && which == L_GENERAL && blockIdx.x == 0 && threadIdx.x == 0) {
-        // fused order: the lists the LAST launches of the previous step consumed (its direct resets, behind the epilogue) are
-        // cleared by the first kernel of this one; everything else is cleared by the epilogue's last block
-        d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u;
-    }
-    // bucket 1: the touching bucket starts at a block boundary (waves of one kind); bucket 2: the touching envs — the ones
-    // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
-    // of the first q entries floor(q * c1 / total) come from the touching list
-    const bool spread = d.bucket == 2;
-    const uint64_t c0_up = spread ? c0 : (c0 + BLK - 1) / BLK * BLK;
-    const uint64_t total = c0_up + c1;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * BLK; q0 < total; q0 += (uint64_t)gridDim.x * BLK) {  // block-uniform
+    mem.vc = &S.vc[own]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNearLds ? d.vc_near : kVcNearLds; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
+    mem.vc_far = far_lane0 + own; mem.vc_far_stride = far_stride;
+    const uint64_t total = CL.c0_up + CL.c1;
+    for (uint64_t q0 = q_first; q0 < total; q0 += q_stride) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
-        const bool have = env_lane && (q < c0 || (q >= c0_up && q < total));
+        const bool have = env_lane && (q < CL.c0 || (q >= CL.c0_up && q < total));
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
         bool stepping = false;      // this lane is inside world.step
         bool step_complete = true;  // ... and has finished it (false only with toi_budget >= 0: profiling)
         World w_local;
-        World& w = kWorldLds ? s_world[kWorldLds ? own : 0] : w_local;
+        World& w = kWorldLds ? S.world[kWorldLds ? own : 0] : w_local;
         EnvRegs e;
         uint32_t action = 0u;
         if (have) {
-            if (spread) {
-                const uint64_t h0 = q * c1 / total, h1 = (q + 1) * c1 / total;
-                i = h1 > h0 ? list[d.n_pad - 1u - h0] : list[q - h0];
-            } else {
-                i = q < c0 ? list[q] : list[d.n_pad - 1u - (q - c0_up)];
-            }
-            w.t = (LL_LDS WorldTmp*)s_tmp + own;
+            i = ll_list_entry(CL, q, total);
+            w.t = (LL_LDS WorldTmp*)S.tmp + own;
             ll_load(d, i, w, e, hot);
             if (!e.has_world) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
                 not_reset = true;
@@ -313,7 +322,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                 if (io.trunc_out) io.trunc_out[i] = 0;
             } else {
                 action = io.act[i];
-                if (w.resume) {   // the free-flight kernel has taken this step up to the end of the island solve (ll_free.h)
+                if (w.resume) {   // the free-flight path has taken this step up to the end of the island solve (ll_free.h)
                     ll_resume_after_island(w);
                 } else {
                     float d0, d1, m_power, s_power;
@@ -341,11 +350,11 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                     for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
                     const int n_tasks = __shfl(incl, 63);
                     const int offs = incl - n_need;
-                    for (int j = 0; j < n_need; ++j) s_task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)s_tmp + own)->idx[1][j]);
+                    for (int j = 0; j < n_need; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
                     __syncthreads();
                     for (int t = (int)threadIdx.x; t < n_tasks; t += kThreads) {
-                        const uint32_t task = s_task[t];
-                        toi_evaluate(s_world[task >> 4], tab, (int)(task & 15u));
+                        const uint32_t task = S.task[t];
+                        toi_evaluate(S.world[task >> 4], tab, (int)(task & 15u));
                     }
                     __syncthreads();
                     if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
@@ -364,7 +373,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
                 ll_emit(d, io, i, state, reward, done);
                 is_done = done != 0u;
                 to_reset = d.auto_reset && done;
-                if (to_reset) d.env_class[i] = 2;   // (see ll_free_kernel)
+                if (to_reset) d.env_class[i] = 2;   // (see ll_free_pass)
             } else {
                 ll_store(d, i, w, e, true);
                 to_toi = true;
@@ -375,10 +384,41 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
         ll_push(d, L_RESET, to_reset, (uint32_t)i);
         finished += (uint32_t)__popcll(__ballot(is_done));
     }
+}
+
+__device__ __forceinline__ void ll_report(const LLDev& d, bool not_reset, uint32_t overflow, uint32_t finished) {
     ll_flush_done(d, finished);
     if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
     if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
     if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
+}
+
+// The contact path as a launch of its own (`which` = L_GENERAL, or L_LATE for the second launch of the overlapped order)
+template <int BLK>
+__global__ void __launch_bounds__(ll_contact_threads(BLK)) LL_CONTACT_ATTR
+ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
+    __shared__ ContactLds<BLK> S;
+    stage_tab(S.tab, LLK(d));
+    bool not_reset = false;
+    uint32_t overflow = 0u, finished = 0u;
+    ContactList CL;
+    CL.list = d.work_list + (uint64_t)which * d.n_pad;  // L_GENERAL (two-ended) or L_LATE
+    CL.back = d.n_pad - 1u;
+    CL.c0 = d.work_count[which]; CL.c1 = which == L_GENERAL ? d.work_count[L_GENERAL_T] : 0u;
+    if (d.fused_tail && which == L_GENERAL && blockIdx.x == 0 && threadIdx.x == 0) {
+        // fused order: the lists the LAST launches of the previous step consumed (its direct resets, behind the epilogue) are
+        // cleared by the first kernel of this one; everything else is cleared by the epilogue's last block
+        d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u;
+    }
+    // bucket 1: the touching bucket starts at a block boundary (waves of one kind); bucket 2: the touching envs — the ones
+    // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
+    // of the first q entries floor(q * c1 / total) come from the touching list
+    CL.spread = d.bucket == 2;
+    CL.c0_up = CL.spread ? CL.c0 : (CL.c0 + BLK - 1) / BLK * BLK;
+    // the two contact launches of the overlapped order run at the same time: each has its own slice of the workspace
+    ll_contact_body<BLK>(d, io, toi_budget, CL, (uint64_t)blockIdx.x * BLK, (uint64_t)gridDim.x * BLK,
+                         (which == L_LATE ? d.vc_far_late : d.vc_far) + (uint64_t)blockIdx.x * BLK, (int)(gridDim.x * BLK), S, not_reset, overflow, finished);
+    ll_report(d, not_reset, overflow, finished);
 }
 
 // Stage 3 of mgym_step, rounds r = 0 .. kToiRounds-1 over ever shorter lists: continue b2World::SolveTOI of the envs on
@@ -522,6 +562,40 @@ ll_general_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uin
 // the scene is a pure function of (seed, env id, episode), and the episode counter only advances on success.
 // Keeping resets out of ll_general_kernel matters because nearly every one of its blocks holds a finishing env:
 // an inline reset made every block pay a second full world step.
+// (hot: this lane's staged contact words; one pass of the lanes of a wave over entries q of the list, or over env q itself)
+__device__ __forceinline__ void ll_reset_pass(const LLDev& d, const LLIo& io, const PolyTab& tab, const CtHot& hot, const uint32_t* __restrict__ list, uint64_t q, uint64_t total, int slow_list) {
+    uint64_t i = q;
+    bool slow = false;
+    if (q < total) {
+        if (list) i = list[q];
+        if (d.episode_src) ST(C_EPISODE) = d.episode_src[(uint64_t)C_EPISODE * d.n_pad + i];  // preparing in the shadow columns: the episode to draw is the live one
+        V2 force; float torque;
+        {
+            World w; EnvRegs e;
+            w.t = nullptr;  // (a reset never reaches the contact path)
+            ll_load(d, i, w, e, hot);
+            ll_reset_scene(d, i, w, e, tab);
+            force = w.b[0].force; torque = w.b[0].torque;  // the initial random push (:845-849) is not a state column
+            ll_store(d, i, w, e);
+        }
+        FreeRegs f; EnvRegs e;
+        ll_free_load(d, i, f, e);
+        f.b[0].force = force; f.b[0].torque = torque;
+        float state[8], reward, d0, d1; uint32_t done;
+        ll_dispersion(d, i, e, d0, d1);
+        uint32_t moved;
+        if (ll_free_env_step(d, i, f, e, tab, 0u, d0, d1, state, reward, done, moved) == FREE_DONE) {
+            e.episode += 1u;
+            ll_free_store(d, i, f, e);
+            ll_write_obs(d, io, i, state);
+        } else {
+            slow = true;
+        }
+    }
+    ll_push(d, slow_list, slow, (uint32_t)i | kWorkReset);
+    if (d.prep && list) ll_push(d, L_PREP, q < total && !slow, (uint32_t)i);
+}
+
 template <int BLK>
 __global__ void __launch_bounds__(BLK)
 ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, int slow_list) {
@@ -529,39 +603,71 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
     LL_HOT_DECL(BLK);
     stage_tab(tab, LLK(d));
     const uint64_t total = list ? (uint64_t)*count : d.n;
-    for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x) {  // block-uniform
-        const uint64_t q = q0 + threadIdx.x;
-        uint64_t i = q;
-        bool slow = false;
-        if (q < total) {
-            if (list) i = list[q];
-            if (d.episode_src) ST(C_EPISODE) = d.episode_src[(uint64_t)C_EPISODE * d.n_pad + i];  // preparing in the shadow columns: the episode to draw is the live one
-            V2 force; float torque;
-            {
-                World w; EnvRegs e;
-                w.t = nullptr;  // (a reset never reaches the contact path)
-                ll_load(d, i, w, e, hot);
-                ll_reset_scene(d, i, w, e, tab);
-                force = w.b[0].force; torque = w.b[0].torque;  // the initial random push (:845-849) is not a state column
-                ll_store(d, i, w, e);
-            }
-            FreeRegs f; EnvRegs e;
-            ll_free_load(d, i, f, e);
-            f.b[0].force = force; f.b[0].torque = torque;
-            float state[8], reward, d0, d1; uint32_t done;
-            ll_dispersion(d, i, e, d0, d1);
-            uint32_t moved;
-            if (ll_free_env_step(d, i, f, e, tab, 0u, d0, d1, state, reward, done, moved) == FREE_DONE) {
-                e.episode += 1u;
-                ll_free_store(d, i, f, e);
-                ll_write_obs(d, io, i, state);
-            } else {
-                slow = true;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * blockDim.x; q0 < total; q0 += (uint64_t)gridDim.x * blockDim.x)  // block-uniform
+        ll_reset_pass(d, io, tab, hot, list, q0 + threadIdx.x, total, slow_list);
+}
+
+// ---- the whole step in ONE launch ---------------------------------------------------------------------------------------------
+// Blocks of one wave each, three roles by block index, all on the caller's stream — no helper streams, no events, nothing a
+// hipGraph executor or the number of hardware queues could serialise:
+//   [0, g_contact)   the contact path over L_GENERAL (ll_contact_body); dispatched first, so the step's longest dependent chains
+//                    start at once on SIMDs of their own
+//   [.., + g_free)   the free-flight path over everyone else, 64 envs per wave; the few envs a wave has to hand to the contact path
+//                    (a contact is created at the end of their step) it takes through ll_contact_body ITSELF, right away, from
+//                    the post-solve state it has just stored (F_RESUME)
+//   [.., + g_prep)   staged resets: the next episode of the envs the previous call's epilogue listed (L_PREP), into the shadow
+//                    columns; these blocks come last and run when SIMDs fall free
+// One register allocation serves all three (512 registers, one wave per SIMD — what the contact path needs; the free-flight
+// path measures the same at that occupancy: profiles/r02_lunarlander/tune_free_kernel_occupancy_overlapped.txt).
+template <int BLK>
+__global__ void __launch_bounds__(64) LL_CONTACT_ATTR
+ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) {
+    static_assert(BLK <= 32, "single-launch step: World records in LDS");
+    __shared__ ContactLds<BLK> S;
+    bool not_reset = false;
+    uint32_t overflow = 0u, finished = 0u;
+    if (blockIdx.x < g_contact) {
+        ContactList CL;
+        CL.list = d.work_list + (uint64_t)L_GENERAL * d.n_pad; CL.back = 0; CL.c0 = d.work_count[L_GENERAL]; CL.c1 = 0; CL.spread = false;
+        CL.c0_up = (CL.c0 + BLK - 1) / BLK * BLK;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u; }   // (consumed by the last launches of the previous call)
+        if ((uint64_t)blockIdx.x * BLK >= CL.c0) return;   // most blocks of this role: the list is far shorter than the grid
+        stage_tab(S.tab, LLK(d));
+        ll_contact_body<BLK>(d, io, -1, CL, (uint64_t)blockIdx.x * BLK, (uint64_t)g_contact * BLK, d.vc_far + (uint64_t)blockIdx.x * BLK, (int)(g_contact * BLK),
+                             S, not_reset, overflow, finished);
+    } else if (blockIdx.x < g_contact + g_free) {
+        const unsigned fb = blockIdx.x - g_contact;
+        stage_tab(S.tab, LLK(d));
+        for (uint64_t base = (uint64_t)fb * 64; base < d.n; base += (uint64_t)g_free * 64) {  // wave-uniform trip count
+            const bool to_general = ll_free_pass(d, io, S.tab, base, not_reset, finished);
+            const unsigned long long hand = __ballot(to_general);
+            if (hand != 0ull) {   // (about one wave in five)
+                if (to_general) S.late[__popcll(hand & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)(base + threadIdx.x);
+                __syncthreads();
+                ContactList CL;
+                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)__popcll(hand); CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
+                ll_contact_body<BLK>(d, io, -1, CL, 0, BLK, d.vc_far_late + (uint64_t)fb * BLK, (int)(g_free * BLK), S, not_reset, overflow, finished);
+                __syncthreads();
             }
         }
-        ll_push(d, slow_list, slow, (uint32_t)i | kWorkReset);
-        if (d.prep && list) ll_push(d, L_PREP, q < total && !slow, (uint32_t)i);
+    } else {
+        const unsigned pb = blockIdx.x - g_contact - g_free, g_prep = gridDim.x - g_contact - g_free;
+        stage_tab(S.tab, LLK(d));
+        const uint32_t* list = d.work_list + (uint64_t)L_PREP * d.n_pad;
+        const uint64_t total = d.work_count[L_PREP];
+        const LLIo none{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (threadIdx.x < BLK) {   // (the staged contact words of a reset: BLK columns)
+            const CtHot hot{(LL_LDS uint32_t*)S.hot + threadIdx.x, (uint32_t)BLK, 1u};
+            for (uint64_t q0 = (uint64_t)pb * BLK; q0 < total; q0 += (uint64_t)g_prep * BLK)
+                ll_reset_pass(sh, none, S.tab, hot, list, q0 + threadIdx.x, total, (int)L_PREP_SLOW);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {   // the last block of this role clears the list it has consumed (the epilogue behind us fills it again)
+            const uint32_t ticket = atomicAdd(d.work_count + C_TICKET2, 1u);
+            if (ticket == g_prep - 1) { d.work_count[L_PREP] = 0u; d.work_count[L_PREP_SLOW] = 0u; d.work_count[C_TICKET2] = 0u; }
+        }
     }
+    ll_report(d, not_reset, overflow, finished);
 }
 
 // Staged resets.  The state an env has after reset() — scene, implicit step(0), observation — is a pure function of
@@ -770,6 +876,8 @@ struct LunarLanderEnv final : Env {
     // can a finished env need the direct path, and only then does step() launch its two (normally empty) kernels behind the epilogue.
     bool direct_possible = true;
     bool prep_due = false;              // a preparation has been marked (mark_prepare) and not launched yet
+    bool ev_prep_valid = false;
+    int staged_in_graph = getenv("MGYM_LL_STAGED_IN_GRAPH") ? atoi(getenv("MGYM_LL_STAGED_IN_GRAPH")) : 1;  // fused order: captured steps keep the staged resets (0: they reset directly)
     bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
     int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
     uint8_t* env_class = nullptr;       // [n] class of each env for this step (ll_classify_kernel): 0 free flight, 1 contact path
@@ -789,6 +897,7 @@ struct LunarLanderEnv final : Env {
     int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int fused_tail = getenv("MGYM_LL_FUSED_TAIL") ? atoi(getenv("MGYM_LL_FUSED_TAIL")) : 1;  // 1 (default): the fused order of step() (ll_epilogue_kernel); needs the overlapped order and none of the profiling knobs
+    int single_launch = getenv("MGYM_LL_SINGLE_LAUNCH") ? atoi(getenv("MGYM_LL_SINGLE_LAUNCH")) : 1;  // 1 (default): contact path, free-flight path and reset preparation in ONE launch (ll_step_kernel); needs the fused order and 32-lane contact blocks
     int resume = getenv("MGYM_LL_RESUME") ? atoi(getenv("MGYM_LL_RESUME")) : 1;  // 1 (default): envs the free-flight kernel stops at a new contact are resumed after their island solve (0: redone from the old state)
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
@@ -842,6 +951,7 @@ struct LunarLanderEnv final : Env {
         dev.resume = resume && !general_only;
         fused_tail = fused_tail && overlap && !general_only && toi_rounds == 0 && bucket == 0;
         dev.fused_tail = fused_tail;
+        single_launch = single_launch && fused_tail && gen_block == 32 && resume;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
         MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
@@ -854,7 +964,8 @@ struct LunarLanderEnv final : Env {
         if (vc_near_limit > kVcNearLds) vc_near_limit = kVcNearLds;
         {
             const size_t per_lane = (size_t)(kSolverCap - vc_near_limit);
-            const size_t lanes_main = (size_t)main_contact_grid() * gen_block, lanes_late = (size_t)late_contact_grid() * 32;
+            // (single-launch step: every wave of the free-flight role may take envs through the contact path itself: a slice per such block)
+            const size_t lanes_main = (size_t)main_contact_grid() * gen_block, lanes_late = (size_t)(single_launch ? grid().x : late_contact_grid()) * 32;
             MGYM_HIP(hipMalloc(&vc_far_base, per_lane * (lanes_main + lanes_late) * sizeof(VConstraint)));
             dev.vc_far = static_cast<VConstraint*>(vc_far_base);
             dev.vc_far_late = dev.vc_far + per_lane * lanes_main;
@@ -891,39 +1002,55 @@ struct LunarLanderEnv final : Env {
         return MGYM_OK;
     }
     bool staging() const { return staged && dev.disp == nullptr; }  // (a dispersion override would be baked into prepared states)
-    // ... and not while the caller's stream is being captured: replayed as a hipGraph the third branch costs more than it
-    // saves (the graph executor keeps neither the stream priorities nor, reliably, the overlap: up to 2.00 ms per step against
-    // 1.49 at 262 144 envs, profiles/r02_lunarlander/launch_modes.txt), so captured steps reset directly; their envs' prepared
-    // states are then simply stale (episode check) the next time a step runs eagerly.
-    bool staging_now() const {
-        if (!staging()) return false;
+    bool capturing() const {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess) return false;
-        return cs == hipStreamCaptureStatusNone;
+        return cs != hipStreamCaptureStatusNone;
     }
+    // Staged resets while the caller's stream is being captured: the fused order takes its preparation branch into the graph (every
+    // event it needs is recorded inside the capture: see step()); the unfused order resets directly in captured steps — replayed as a
+    // hipGraph its extra branch cost more than it saved (profiles/r02_lunarlander/launch_modes.txt) — and their envs' prepared states
+    // are then simply stale (episode check) the next time a step runs eagerly.
+    bool staging_now() const {
+        if (!staging()) return false;
+        return (fused_tail && staged_in_graph) || !capturing();
+    }
+    // Preparation state.  prep_due: L_PREP may hold envs (put there by an epilogue) that no preparation launch has been issued for;
+    // ev_prep_valid: ev_prep is a real record on `stream` behind that epilogue (a record made while capturing is not);
+    // prep_pending: a launch is on aux2 that `stream` has not waited for yet (never true between calls).
     // `stream` waits for the preparation work put on aux2 so far: before anything appends to L_PREP or reads the shadow columns
     int join_helpers() override {
-        if (prep_due) { int st = launch_prepare(false, true, false); if (st != MGYM_OK) return st; }   // marked by the last step, no step followed
+        if (prep_due && !capturing()) {   // marked by the last step, no step followed
+            int st = launch_prepare(false, true, false);
+            if (st != MGYM_OK) return st;
+        }
         if (prep_pending) { MGYM_HIP(hipStreamWaitEvent(stream, ev_prepared, 0)); prep_pending = false; }
         return MGYM_OK;
     }
     // prepare the next reset of the envs on L_PREP (or of every env), after what `stream` holds so far.
-    // Fused order: the preparation that follows a step is only MARKED here (event recorded) and launched by the next step()
-    // behind its free-flight kernel (after_free) — started at once it competes with the contact kernel for the SIMDs at the very
-    // moment that kernel's one-wave-per-SIMD blocks are being placed (contact kernel 1.04 -> 1.15 ms, itself 0.11 -> 0.7 ms).
-    int mark_prepare() {
-        MGYM_HIP(hipEventRecord(ev_prep, stream));
+    // Fused order: the preparation that follows a step is only MARKED (mark_prepare) and launched by the next step() behind its
+    // free-flight kernel (after_free) — started at once it competes with the contact kernel for the SIMDs at the very moment that
+    // kernel's one-wave-per-SIMD blocks are being placed (contact kernel 1.04 -> 1.15 ms, itself 0.11 -> 0.7 ms).
+    int mark_prepare(bool in_capture) {
+        if (!in_capture) MGYM_HIP(hipEventRecord(ev_prep, stream));
+        ev_prep_valid = !in_capture;
         prep_due = true;
         return MGYM_OK;
     }
-    int launch_prepare(bool all, bool deferred = false, bool after_free = false) {
+    // deferred: the launch belongs to an earlier mark_prepare (no new record of ev_prep, unless that one was made while capturing);
+    // in_capture: everything this launch waits for is recorded inside the capture (ev_free_done), and what it prepares is whatever
+    // L_PREP holds when the graph runs
+    int launch_prepare(bool all, bool deferred = false, bool after_free = false, bool in_capture = false) {
         LLDev sh = dev;
         sh.st = static_cast<uint32_t*>(shadow_base); sh.obs = static_cast<float*>(shadow_obs);
         sh.episode_src = dev.st; sh.prep = 0; sh.split = 0;
         const LLIo none{nullptr, nullptr, nullptr, nullptr, nullptr};
-        if (!deferred) MGYM_HIP(hipEventRecord(ev_prep, stream));
-        prep_due = false;
-        MGYM_HIP(hipStreamWaitEvent(aux2, ev_prep, 0));
+        if (!in_capture) {
+            if (!deferred || !ev_prep_valid) MGYM_HIP(hipEventRecord(ev_prep, stream));
+            ev_prep_valid = true;
+            prep_due = false;
+            MGYM_HIP(hipStreamWaitEvent(aux2, ev_prep, 0));
+        }
         if (after_free) MGYM_HIP(hipStreamWaitEvent(aux2, ev_free_done, 0));
         if (all) hipLaunchKernelGGL(ll_reset_kernel<64>, grid(), dim3(64), 0, aux2, sh, none, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)L_PREP_SLOW);
         else hipLaunchKernelGGL(ll_reset_kernel<32>, dim3(work_grid().x * 2), dim3(32), 0, aux2, sh, none, list_ptr(L_PREP), (const uint32_t*)dev.work_count + L_PREP, (int)L_PREP_SLOW);
@@ -974,11 +1101,15 @@ struct LunarLanderEnv final : Env {
         if (general_only && all) {  // debugging aid: reset + implicit step on the general path
             hipLaunchKernelGGL(ll_general_kernel<64>, grid(), dim3(kLLBlock), 0, stream, dev, io, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1);
         } else {
-            const bool stage = staging_now();
+            const bool stage = staging_now() && !capturing();   // (a captured reset computes directly and prepares nothing)
             if (stage) { int st = join_helpers(); if (st != MGYM_OK) return st; }
             if (!all) hipLaunchKernelGGL(ll_mask_scan_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dev, m0, m1);
             launch_resets(io, all, L_RESET, stage);
-            if (stage) { int st = launch_prepare(all); if (st != MGYM_OK) return st; }
+            if (stage) {   // (waited for at once: between calls nothing is left pending on the helper streams)
+                int st = launch_prepare(all);
+                if (st == MGYM_OK) st = join_helpers();
+                if (st != MGYM_OK) return st;
+            }
             if (stage && all) direct_possible = false;   // every env has a fitting prepared successor from here on
             else if (!stage) direct_possible = true;     // (a masked staged reset prepares the envs it resets and says nothing about the others: unchanged)
         }
@@ -1026,14 +1157,42 @@ struct LunarLanderEnv final : Env {
             // the contact kernel starts at once; beside it, on the helper stream, the free-flight kernel and the short contact launch
             // for the envs it hands over; after the join ONE epilogue launch: prepared resets copied in, next step's list, counters.
             LLDev sd = dev; sd.split = 1;
+            if (single_launch) {
+                // ONE launch for the step (ll_step_kernel) and one for its end (ll_epilogue_kernel), both on the caller's stream: no
+                // helper streams, no events — nothing depends on hardware queues or on how a graph executor schedules branches.
+                const bool stage1 = dev.auto_reset && staging();
+                LLDev sh = sd;
+                if (stage1) {
+                    sh.st = static_cast<uint32_t*>(shadow_base); sh.obs = static_cast<float*>(shadow_obs);
+                    sh.episode_src = dev.st; sh.prep = 0; sh.split = 0;
+                }
+                const unsigned g_contact = gb, g_free = grid().x, g_prep = stage1 ? 128u : 0u;
+                hipLaunchKernelGGL(ll_step_kernel<32>, dim3(g_contact + g_free + g_prep), dim3(64), 0, stream, sd, sh, io, g_contact, g_free);
+                LLIo rio1{nullptr, obs_out, nullptr, nullptr, nullptr};
+                if (stage1) {
+                    hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio1, 1, direct_possible ? 1 : 0);
+                    if (direct_possible) launch_resets(rio1, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
+                } else {
+                    if (dev.auto_reset) launch_resets(rio1, false);
+                    if (dev.auto_reset && staged) direct_possible = true;   // resets computed here leave no prepared successor behind
+                    hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)nullptr, (const float*)nullptr, rio1, 0, 1);
+                }
+                MGYM_HIP(hipGetLastError());
+                return MGYM_OK;
+            }
+            const bool stage = dev.auto_reset && staging_now();
+            const bool cap = stage && capturing();
+            if (stage && !cap && prep_due && !ev_prep_valid) {   // marked by a captured step: the record has to be made now, BEFORE this step's contact kernel
+                MGYM_HIP(hipEventRecord(ev_prep, stream));
+                ev_prep_valid = true;
+            }
             MGYM_HIP(hipEventRecord(ev_fork, stream));
             launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
             MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             launch_free(aux, sd, io);
-            const bool stage = dev.auto_reset && staging_now();
-            if (stage && prep_due) {   // the preparation the previous step marked: behind the free-flight kernel, beside the late contact launch
+            if (stage && (cap || prep_due)) {   // the preparation the previous step marked: behind the free-flight kernel, beside the late contact launch
                 MGYM_HIP(hipEventRecord(ev_free_done, aux));
-                int st = launch_prepare(false, true, true);
+                int st = launch_prepare(false, true, true, cap);
                 if (st != MGYM_OK) return st;
             }
             launch_contact(aux, 32, late_contact_grid(), sd, io, -1, L_LATE);
@@ -1045,7 +1204,7 @@ struct LunarLanderEnv final : Env {
                 if (st != MGYM_OK) return st;
                 hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1, direct_possible ? 1 : 0);
                 if (direct_possible) launch_resets(rio, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
-                st = mark_prepare();
+                st = mark_prepare(cap);
                 if (st != MGYM_OK) return st;
             } else {
                 if (dev.auto_reset) launch_resets(rio, false);
@@ -1112,7 +1271,7 @@ struct LunarLanderEnv final : Env {
     }
     // mgym_get_info: the launch structure of this handle and whether its streams really run side by side
     int info(std::string& out) override {
-        out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (overlap ? "overlapped" : "sequential") +
+        out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
                "\nstaged_resets=" + (staged ? "1" : "0") + "\n";
         hipStream_t ss[3] = {stream, aux, aux2};
         const int ns = aux2 ? 3 : 2;
