@@ -47,8 +47,7 @@ def parse():
                     choices=["cartpole", "mountain_car", "mountain_car_cont", "lunar_lander", "mixed"])
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: BASELINE size)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
-                    help="auto: hipGraph replay for the launch-bound families (CartPole, MountainCar: ~10 us steps); eager for LunarLander, "
-                         "whose ~1.5 ms step hides the launch latency and whose prepared resets run on a side stream only outside graphs")
+                    help="auto: hipGraph replay (every family; LunarLander populations that use the multi-stream launch order stay eager)")
     ap.add_argument("--reset", default="fused", choices=["fused", "separate"],
                     help="fused: auto-reset inside the step kernel; separate: step + mgym_reset_done launch")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -102,12 +101,14 @@ def dry_run_launch(args, rank, local_rank, world, real_stdout):
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
-def launch_mode(requested, family):
-    """`--launch auto`: hipGraph replay for the launch-bound families, eager launches for LunarLander (a ~1.5 ms step hides the
-    launch latency; its prepared resets use a side stream only outside graphs)."""
+def launch_mode(requested, family, launch_order="single_launch"):
+    """`--launch auto`: hipGraph replay for every family.  CartPole / MountainCar steps are ~10 us (launch-bound); a LunarLander step is
+    two launches on the caller's stream (`launch_order` of mgym_get_info = single_launch), which a graph replays exactly as eager
+    launches run (profiles/r03_lunarlander/launch_modes.txt).  Only populations that select the multi-stream order (64-lane contact
+    blocks, from 360 448 envs) stay eager: a graph executor serialises its side branches."""
     if requested != "auto":
         return requested
-    return "eager" if family == "lunar_lander" else "graph"
+    return "eager" if (family == "lunar_lander" and launch_order != "single_launch") else "graph"
 
 
 class Stepper:
@@ -117,10 +118,11 @@ class Stepper:
         kinds = {"cartpole": (mg.CARTPOLE, 2), "mountain_car": (mg.MOUNTAINCAR, 3),
                  "mountain_car_cont": (mg.MOUNTAINCAR_CONT, 0), "lunar_lander": (mg.LUNARLANDER, 4)}
         kind, nact = kinds[kind_name]
-        self.name, self.n, self.reset_mode, self.launch = kind_name, n, reset_mode, launch_mode(launch, kind_name)
+        self.name, self.n, self.reset_mode = kind_name, n, reset_mode
         extra = dict(enable_wind=True) if kind_name == "lunar_lander" else {}
         self.env = mg.VecEnv(kind, n, device=device, seed=seed, env_id_base=base, auto_reset=(reset_mode == "fused"),
                              stream=stream.cuda_stream, **extra)
+        self.launch = launch_mode(launch, kind_name, self.env.info().get("launch_order", "") if kind_name == "lunar_lander" else "")
         g = torch.Generator(device=f"cuda:{device}")
         g.manual_seed(seed & 0x7FFFFFFF)
         if nact:
@@ -479,8 +481,8 @@ def main():
         # the other BASELINE configs, measured AFTER the timed region (never the headline `value`)
         extra = {}
         for name, cnt, k in (("mountain_car", 1 << 20, 400), ("mountain_car_cont", 1 << 20, 400), ("lunar_lander", 1 << 18, 128),
-                             ("cartpole_32Mi_envs_hbm_regime", 1 << 25, 96)):
-            wl = "cartpole" if name.startswith("cartpole") else name
+                             ("cartpole_32Mi_envs_hbm_regime", 1 << 25, 96), ("mountain_car_32Mi_envs_hbm_regime", 1 << 25, 96)):
+            wl = "cartpole" if name.startswith("cartpole") else ("mountain_car" if name.startswith("mountain_car_32Mi") else name)
             st = Stepper(mg, torch, wl, cnt, local_rank, args.seed + 7, 0, stream, args.reset, args.launch)
             st.run(640 if wl == "lunar_lander" else RING * 2)   # LunarLander: reach the steady mix of flight / contact / resets
             st.env.sync()
@@ -489,10 +491,39 @@ def main():
             st.run(k)
             ms = st.env.timer_stop()
             st.env.sync()
-            rec = {"env_steps_per_s": cnt * k / (ms * 1e-3), "us_per_step": ms * 1e3 / k, "n_envs": cnt, "steps": k}
+            rec = {"env_steps_per_s": cnt * k / (ms * 1e-3), "us_per_step": ms * 1e3 / k, "n_envs": cnt, "steps": k, "launch": st.launch}
             if wl in ALG_BYTES:
                 rec["alg_GBps"] = ALG_BYTES[wl] * cnt * k / (ms * 1e-3) / 1e9
                 rec["hbm_frac"] = rec["alg_GBps"] * 1e9 / HBM_PEAK
+                # the same object the headline carries: dominant kernel, algorithmic bytes per launch / HIP-event time per launch, counter traffic
+                alg1 = ALG_BYTES[wl] * cnt
+                rec["roofline"] = {"bound": "hbm", "achieved": rec["alg_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": rec["hbm_frac"], "traffic": None,
+                                   "kernel": ("cartpole_step_kernel<4>" if wl == "cartpole" else "mountaincar_step4_kernel<%s, true>" % ("true" if wl.endswith("cont") else "false")),
+                                   "alg_bytes_per_launch": alg1, "avg_launch_us": ms * 1e3 / k}
+                prec = pmc_record(f"{wl}:{cnt}")
+                if prec:
+                    rec["roofline"]["traffic"] = prec["hbm_bytes_per_launch"]
+                    rec["roofline"]["traffic_source"] = prec.get("source")
+                if cnt >= (1 << 25):
+                    # memory-side reference on THIS box, in this run: a plain device-to-device copy with the same read + write footprint as one
+                    # launch (what the box's HBM delivers to a kernel with no arithmetic at all; boxes of the pool differ by ~15 % here)
+                    nbytes = alg1 // 2
+                    src = torch.empty(nbytes, device=f"cuda:{local_rank}", dtype=torch.uint8)
+                    dst = torch.empty_like(src)
+                    with torch.cuda.stream(stream):
+                        for _ in range(3):
+                            dst.copy_(src)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                        for _ in range(20):
+                            dst.copy_(src)
+                        e1.record(stream)
+                    e1.synchronize()
+                    cms = e0.elapsed_time(e1) / 20
+                    rec["roofline"]["copy_reference"] = {"GBps": 2 * nbytes / (cms * 1e-3) / 1e9, "us": cms * 1e3, "bytes_read_plus_written": 2 * nbytes,
+                                                         "frac_of_copy": rec["alg_GBps"] / (2 * nbytes / (cms * 1e-3) / 1e9),
+                                                         "note": "torch device-to-device copy of the same footprint, same box, same run"}
+                    del src, dst
             if wl == "lunar_lander":
                 rec["roofline"] = lunar_roofline(cnt, ms * 1e-3 / k)
             extra[name] = rec
@@ -545,11 +576,21 @@ def main():
         # rank, RCCL over xGMI; off the step path, reported on its own (rehearsable on one GPU with MGYM_FORCE_DIST=1)
         from modurl_gym_amd.shard import all_gather_observations, all_reduce_episode_count
         from modurl_gym_amd.torch_env import _DeviceSpan
-        ag = None
+        # Every rank reaches the SAME collectives in the same order whatever happens locally: a rank that fails before a collective
+        # would leave the others blocked in it (and the job without its JSON line).  Local failures and unequal shard sizes
+        # (--scaling strong with a population the world size does not divide) are agreed on first, through one all-reduce.
+        ag, episodes, ag_err, view, local_count = None, None, None, None, 0
         try:
             ptr, stride = lead.env.observation_device()
+            view = torch.as_tensor(_DeviceSpan(ptr, (4, lead.n), (4 * stride, 4), lead), device=f"cuda:{local_rank}")
+            local_count = lead.env.episode_count()
+        except Exception as e:  # noqa: BLE001
+            ag_err = repr(e)
+        agree = torch.tensor([1.0 if ag_err else 0.0, float(lead.n), -float(lead.n)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX)
+        any_failed, equal_shards = float(agree[0]) > 0, float(agree[1]) == -float(agree[2])
+        if not any_failed and equal_shards:
             with torch.cuda.stream(stream):
-                view = torch.as_tensor(_DeviceSpan(ptr, (4, lead.n), (4 * stride, 4), lead), device=f"cuda:{local_rank}")
                 for _ in range(3):
                     all_gather_observations(view, world)
                 torch.cuda.synchronize()
@@ -558,9 +599,13 @@ def main():
                     all_gather_observations(view, world)
                 torch.cuda.synchronize()
                 ag = (time.perf_counter() - t0g) / 20
-            episodes = all_reduce_episode_count(lead.env.episode_count(), device=f"cuda:{local_rank}")
-        except Exception as e:  # noqa: BLE001
-            ag, episodes = None, repr(e)
+        elif not any_failed:
+            ag_err = "shard sizes differ across ranks: all-gather skipped (it takes equal shards)"
+        else:
+            ag_err = ag_err or "failed on another rank"
+        episodes = all_reduce_episode_count(local_count, device=f"cuda:{local_rank}")   # (0 from a rank that failed locally)
+        if ag_err:
+            episodes = {"sum_over_ranks": episodes, "note": ag_err}
         if rank == 0:
             result.setdefault("extra", {})["all_gather_observations"] = {
                 "ms": None if ag is None else ag * 1e3, "bytes_per_rank": lead.n * 16, "world": world,

@@ -1,8 +1,12 @@
-// cartpole_math.h — cheaper instruction sequences for the CartPole step, each PROVEN bit-identical to the
+// cartpole_math.h — cheaper instruction sequences for the CartPole step, each checked bit-identical to the
 // reference-form arithmetic it replaces (cartpole.rs:264-271 evaluated with IEEE f32 divide and the
-// glibc-equal mg_sincosf of mgym_math.h) by exhaustive enumeration:
-//   * tests/native/cartpole_fast_check.cpp (no GPU): every one of the 2^32 f32 inputs of cp_sincos_small and
-//     cp_div_const against mg_sincosf / IEEE `x / c`; cp_div over every divisor the step can form.
+// glibc-equal mg_sincosf of mgym_math.h):
+//   * tests/native/cartpole_fast_check.cpp (no GPU): EXHAUSTIVELY every one of the 2^32 f32 inputs of cp_sincos_small and
+//     cp_div_const against mg_sincosf / IEEE `x / c`.  cp_div (n / d): exhaustive over the DIVISORS the step can form (762 602) and
+//     over every 1-ulp reciprocal estimate, with SAMPLED numerators (24 random + hard values per divisor, 4.4e8 cases) plus the
+//     standard argument for this division expansion (one Newton step on a 1-ulp reciprocal, quotient, two residual corrections are
+//     correctly rounded while no intermediate under- or overflows: numerators in [2^-100, 2^100], which cp_div_range_ok tests and
+//     DESIGN.md §4 derives from the step's guard); the whole fast step against the reference step on 7e7 guard-admitted states.
 //   * tests/test_gpu_classic.py::test_cartpole_fast_math_exhaustive_on_gpu: the same enumerations on the MI355X
 //     (hardware v_rcp_f32, v_fma_f64), so the proof holds for the silicon that runs the kernel.
 // The step kernels use these only under a wave-uniform guard (|theta| < 0.75, |theta_dot| < 2^40, valid action)

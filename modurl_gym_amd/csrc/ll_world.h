@@ -814,13 +814,73 @@ LLD bool toi_state_same(const ToiSweepState& a, const ToiSweepState& b) {
     for (int q = 0; q < 11; ++q) same = same && a.w[q] == b.w[q];
     return same;
 }
+// A third way out, for the states above whose VELOCITY has stopped while an impulse still creeps: the sweeps' only output is the body
+// velocity (b2Island::SolveTOI does not store the impulses), and for one-point constraints it can be PROVEN constant from here on.
+// With the velocity V fixed, every sweep computes the same increments lam_t, lam_n from V; the accumulated impulses then move by at most
+//   |dn| <= lam_n + ulp(n)   (n' = max(n + lam_n, 0): a clamp at 0 moves it by less than lam_n; 0 when lam_n rounds away)
+//   |dt| <= f |dn| + ulp while it slides along the friction bound (t' = clamp(t + lam_t, +-f n)), lam_t + ulp otherwise
+// per sweep, and the velocity update of an impulse d along a unit direction u is v += mB (d u), w += iB cross(rB, d u).  If every one
+// of those six terms, with d at its bound over all remaining sweeps (impulses at most 180 increments larger than now), stays below
+// half the spacing of the floats just below the velocity component it is added to, each addition returns that component unchanged (round to nearest),
+// so by induction over the updates of a sweep and over the sweeps V never changes again: stop.  Components that are exactly zero are
+// excluded (an added zero can change the sign of a zero), as are two-point constraints (their block solver's increments depend on the
+// accumulated impulses through a cancellation).  tests/native/ll_host_check.cpp re-runs every shortened solve in full and compares.
+// A term of magnitude BELOW this, added to x, returns x (round to nearest): half the distance from x to its nearer neighbour — for |x| in
+// (2^k, 2^(k+1)) that is 2^(k-24), for |x| = 2^k exactly 2^(k-25) (the floats below are spaced half as far).  0 when x is zero, denormal,
+// tiny, infinite or NaN.
+LLD float toi_half_spacing(float x) {
+    const uint32_t u = as_u32(x), e = (u >> 23) & 0xffu;
+    const uint32_t down = (u & 0x7fffffu) ? 24u : 25u;
+    return (e > 26u && e < 255u) ? as_f32((e - down) << 23) : 0.0f;
+}
+LLD float toi_half_ulp(float x) {   // an upper bound of the rounding error of a sum that comes out near x: half the spacing of the floats at |x|
+    const uint32_t e = (as_u32(x) >> 23) & 0xffu;
+    return e > 24u ? as_f32((e - 24u) << 23) : 1.0e-37f;
+}
+LLD bool toi_velocity_settled_one(const VConstraint& vc, const Vel& V) {
+    const VCPoint& p = vc.points[0];
+    const V2 nrm = vc.normal, tan = cross_vs(nrm, 1.0f);
+    const V2 dv = V.v + cross_sv(V.w, p.rB);
+    const float lam_t_s = p.tangentMass * (-(dot(dv, tan) - 0.0f)), lam_t = fabs1(lam_t_s);           // as cs_friction_point forms them
+    const float lam_n_s = -p.normalMass * (dot(dv, nrm) - p.velocityBias), lam_n = fabs1(lam_n_s);  // as cs_solve_one forms them
+    const float kSlack = 1.0001f;                                         // the rounding of the bounds themselves
+    const float f = vc.friction, n = p.normalImpulse, t = p.tangentImpulse, at = fabs1(t);
+    // the normal impulse, n' = max(n + lam_n_s, 0).  An increment below half the spacing of the floats around n rounds away (n never moves
+    // again); at n = 0 a non-positive increment is clamped away; otherwise it moves by the increment and the rounding of the sum
+    float Bn, n_max;
+    if ((n > 0.0f && lam_n < toi_half_spacing(n)) || (n == 0.0f && lam_n_s <= 0.0f)) { Bn = 0.0f; n_max = n; }
+    else { n_max = (n + 180.0f * lam_n) * kSlack; Bn = (lam_n + toi_half_ulp(n_max)) * kSlack; }
+    // the tangent impulse, t' = clamp(t + lam_t_s, -M, M), M = f n.  Sliding (pushed outward by more than M can move): t' = +-M every
+    // sweep, so it moves by what separates it from the bound now and by f |dn| afterwards; otherwise by the increment
+    const float M = f * n, D0 = fabs1(M - at);
+    const bool outward = (lam_t_s < 0.0f && t <= 0.0f) || (lam_t_s > 0.0f && t >= 0.0f);
+    const float m_err = Bn == 0.0f ? 0.0f : toi_half_ulp(f * n_max);   // the rounding of M = f n while n moves
+    const float slide = (fmax2(D0, f * Bn) + m_err) * kSlack;
+    float Bt;
+    if (outward && lam_t > 2.0f * slide + 4.0f * toi_half_ulp(at + M)) Bt = slide;
+    else { const float step = fmax2(lam_t, f * Bn); Bt = (step + toi_half_ulp((at + 180.0f * step) * kSlack) + m_err) * kSlack; }
+    const float mB = vc.invMassB, iB = vc.invIB;
+    const float ax = fabs1(nrm.x), ay = fabs1(nrm.y), rx = fabs1(p.rB.x), ry = fabs1(p.rB.y);
+    // (0.999 of the half spacing: the rounding of the products on both sides of the comparison)
+    const float vx = 0.999f * toi_half_spacing(V.v.x), vy = 0.999f * toi_half_spacing(V.v.y), vw = 0.999f * toi_half_spacing(V.w);
+    bool ok = vx > 0.0f && vy > 0.0f && vw > 0.0f;                        // (false for zero, denormal, tiny, infinite and NaN velocities)
+    ok = ok && Bn * (mB * ax) <= vx && Bn * (mB * ay) <= vy && Bn * (iB * (rx * ay + ry * ax)) <= vw;   // normal impulse: along n
+    ok = ok && Bt * (mB * ay) <= vx && Bt * (mB * ax) <= vy && Bt * (iB * (rx * ax + ry * ay)) <= vw;   // tangent impulse: along (n.y, -n.x)
+    return ok;
+}
+
 LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
     Vel vd = vd_io;
     VConstraint r0, r1;
     const bool h0 = cs.count > 0, h1 = cs.count > 1;
     if (h0) r0 = cs_vc(cs, 0);
     if (h1) r1 = cs_vc(cs, 1);
+#ifdef LL_TOI_SWEEP_VERIFY
+    const Vel v_in = vd; const VConstraint r0_in = r0, r1_in = r1;
+#endif
     bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
+    const bool can_settle = can_stop && (!h0 || r0.pointCount == 1) && (!h1 || r1.pointCount == 1);
+    int settle_at = 2;              // the proof is tried when the velocity has not moved during a sweep, with exponential back-off
     auto state_now = [&]() {
         ToiSweepState st;
         st.w[0] = as_u32(vd.v.x); st.w[1] = as_u32(vd.v.y); st.w[2] = as_u32(vd.w);
@@ -850,11 +910,22 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
             if (toi_state_same(cur, prev)) break;                                                // fixed point
             if (toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
             else if (done == next_snap) { snap = cur; snap_at = done; next_snap *= 2; }
+            if (can_settle && can_stop && done >= settle_at && cur.w[0] == prev.w[0] && cur.w[1] == prev.w[1] && cur.w[2] == prev.w[2]) {
+                if ((!h0 || toi_velocity_settled_one(r0, vd)) && (!h1 || toi_velocity_settled_one(r1, vd))) break;   // the velocity is final
+                settle_at = 2 * done;
+            }
             prev = cur;
         }
     }
     LL_DIAG_SWEEP_END(1);
     LL_TOI_SWEEP_STAT(cs.count, done);
+#ifdef LL_TOI_SWEEP_VERIFY
+    if (cs.count <= 2) {
+        Vel vp = v_in; VConstraint q0 = r0_in, q1 = r1_in;
+        for (int it = 0; it < 180; ++it) { if (h0) cs_solve_one(q0, vp); if (h1) cs_solve_one(q1, vp); }
+        LL_TOI_SWEEP_VERIFY(vp, vd, done);
+    }
+#endif
     vd_io = vd;
 }
 

@@ -348,10 +348,16 @@ static void add_pair(b2world *w, int edge, int body) {
 /* b2BroadPhase::UpdatePairs + b2ContactManager::FindNewContacts.  Brute-force partner search
  * (ascending proxy id) replaces the dynamic-tree query; filtering: ground (cat 1, mask 0xFFFF)
  * collides with lander (0x10/0x1) and legs (0x20/0x1); lander/legs never collide with each other. */
+/* What-if switch for tools/ll_contact_order_probe.py ONLY (quantifies the one documented deviation): Box2D's order of
+ * newly created contacts depends on dynamic-tree traversal; this restatement (and the kernels) use "moved proxies in body-list order,
+ * partner edges by ascending id".  bit 0: partners by DESCENDING id; bit 1: moved proxies in reverse order.  0 = the product's order. */
+int b2mini_order_variant = 0;
 static void find_new_contacts(b2world *w) {
-    for (int i = 0; i < w->move_count; ++i) {
+    for (int ii = 0; ii < w->move_count; ++ii) {
+        int i = (b2mini_order_variant & 2) ? w->move_count - 1 - ii : ii;
         int q = w->move_buffer[i];
-        for (int p = 0; p < B2_N_PROXIES; ++p) {
+        for (int pp = 0; pp < B2_N_PROXIES; ++pp) {
+            int p = (b2mini_order_variant & 1) ? B2_N_PROXIES - 1 - pp : pp;
             if (!w->proxy_exists[p] || p == q) continue;
             if (!aabb_overlap(w->fat[q], w->fat[p])) continue;
             if (w->moved[p] && p > q) continue; /* both moving: avoid duplicate pairs */

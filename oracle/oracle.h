@@ -151,6 +151,8 @@ void ora_vec_set_state(ora_vec *v, const float *soa);
 int ora_vec_reset_deterministic(ora_vec *v, float *obs_soa);
 /* lunar lander only: per-env dispersion override ([2][n] raw draws), NULL = generator */
 void ora_vec_set_dispersion(ora_vec *v, const float *disp_soa);
+/* what-if switch of the contact-creation order (b2mini.c b2mini_order_variant; tools/ll_contact_order_probe.py): process-wide, 0 = normal */
+void ora_set_contact_order_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ def lib():
         L.ora_mountaincar_reset.argtypes = [C.POINTER(MountainCar), C.c_double]
         L.ora_mountaincar_cont_reset.argtypes = [C.POINTER(MountainCarCont), C.c_double]
         L.ora_vec_new.restype = C.c_void_p
+        L.ora_set_contact_order_variant.argtypes = [C.c_int]
         L.ora_vec_new.argtypes = [C.POINTER(VecConfig), C.POINTER(C.c_int)]
         L.ora_vec_free.argtypes = [C.c_void_p]
         L.ora_vec_obs_dim.argtypes = [C.c_void_p]

@@ -328,6 +328,8 @@ void ora_vec_set_state(ora_vec *v, const float *soa) {
 }
 
 void ora_vec_set_dispersion(ora_vec *v, const float *disp_soa) { v->disp_override = disp_soa; }
+extern int b2mini_order_variant;
+void ora_set_contact_order_variant(int variant) { b2mini_order_variant = variant; }
 
 int ora_vec_reset_deterministic(ora_vec *v, float *obs_soa) {
     if (v->cfg.kind != 3) return ORA_BAD_CONFIG;

@@ -10,10 +10,19 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+// every time-of-impact velocity solve that stopped before its 180th sweep (fixed point, cycle, settled-velocity proof) is re-run in
+// full and must give the same velocity bit for bit
+static unsigned long g_verify_total, g_verify_short, g_verify_bad;
+#define LL_TOI_SWEEP_VERIFY(v_full, v_got, done) do { g_verify_total++; if ((done) < 180) g_verify_short++; \
+    if (memcmp(&(v_full).v.x, &(v_got).v.x, 4) || memcmp(&(v_full).v.y, &(v_got).v.y, 4) || memcmp(&(v_full).w, &(v_got).w, 4)) { if (g_verify_bad++ < 5) printf("TOI SWEEP SHORTCUT MISMATCH after %d sweeps: %.9g %.9g %.9g vs %.9g %.9g %.9g\n", (int)(done), (v_got).v.x, (v_got).v.y, (v_got).w, (v_full).v.x, (v_full).v.y, (v_full).w); } } while (0)
+#ifndef LL_TRACE_N
+#define LL_TRACE_N 0
+#define LL_TRACE_COUNT 1
+#endif
 #ifdef LL_HOST_STATS  // -DLL_HOST_STATS: histogram of the sub-step velocity sweeps actually run, by constraint count (tools/ll_work_stats.sh)
 static unsigned long g_toi_sweeps[13][181], g_rounds_by_touch[2][6], g_rounds_by_ncont[9][6];
-#define LL_TOI_SWEEP_STAT(count, done) do { g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++; if ((done) == 180 && g_trace_left > 0) { --g_trace_left; printf("-- a sub-step that ran all 180 sweeps (%d constraints); state words after sweeps 1..180 (v.x v.y w n00 t00 n01 t01 n10 t10 n11 t11):\n", (int)(count)); for (int q_ = 0; q_ < 180; ++q_) if (q_ < 6 || q_ % 20 == 0 || q_ >= 174) { printf("   %3d:", q_ + 1); for (int z_ = 0; z_ < 11; ++z_) printf(" %08x", g_trace[q_][z_]); printf("\n"); } } } while (0)
-static unsigned g_trace[181][11]; static int g_trace_left = 0;
+#define LL_TOI_SWEEP_STAT(count, done) do { g_toi_sweeps[(count) < 12 ? (count) : 12][(done)]++; if ((done) == 180 && g_trace_left > 0 && (count) == LL_TRACE_COUNT) { --g_trace_left; printf("-- a sub-step that ran all 180 sweeps (%d constraints); state words after sweeps 1..180 (v.x v.y w n00 t00 n01 t01 n10 t10 n11 t11):\n", (int)(count)); for (int q_ = 0; q_ < 180; ++q_) if (q_ < 6 || q_ % 20 == 0 || q_ >= 174) { printf("   %3d:", q_ + 1); for (int z_ = 0; z_ < 11; ++z_) printf(" %08x", g_trace[q_][z_]); printf("\n"); } } } while (0)
+static unsigned g_trace[181][11]; static int g_trace_left = LL_TRACE_N;
 static unsigned long g_pos_iters[2][13][61], g_pos_how[2][3];
 static unsigned g_ptrace[60][9]; static unsigned long g_pcycle_at[62], g_pcycle_period[62]; static int g_ptrace_print = 3;
 #define LL_POS_ITER_TRACE(it, pos) do { const float z_[9] = {(pos).b0.c.x, (pos).b0.c.y, (pos).b0.a, (pos).b1.c.x, (pos).b1.c.y, (pos).b1.a, (pos).b2.c.x, (pos).b2.c.y, (pos).b2.a}; memcpy(g_ptrace[(it)], z_, sizeof z_); } while (0)
@@ -151,6 +160,8 @@ int main(int argc, char** argv) {
         }
     }
     printf("envs=%lu steps=%d wind=%d det=%d mismatches=%lu exact_words=%lu/%lu episodes_done=%lu overflow=%lu\n", (unsigned long)n, steps, wind, deterministic, mism, exact, total, done_total, overflow);
+    printf("time-of-impact velocity solves %lu, of which shortened %lu, all re-run in full: %lu differ\n", g_verify_total, g_verify_short, g_verify_bad);
+    if (g_verify_bad) mism += g_verify_bad;
     printf("fast-path steps %lu, general-path steps %lu (of which resumed after the free path's island solve: %lu)\n", fast_steps, general_steps, resumed_steps);
     printf("max simultaneous cached contacts %d; histogram:", max_slots);
     for (int q = 0; q <= kSlots; ++q) printf(" %lu", hist[q]);

@@ -39,10 +39,12 @@ def test_source_hash_ignores_comments_but_not_code():
 
 
 def test_launch_mode_per_family():
-    # --launch auto: hipGraph replay for the launch-bound families, eager launches for LunarLander
+    # --launch auto: hipGraph replay for every family — a LunarLander step is two launches on one stream (single_launch), replayed
+    # exactly as issued; only the multi-stream order of the largest populations stays eager
     assert bench.launch_mode("auto", "cartpole") == "graph" and bench.launch_mode("auto", "mountain_car_cont") == "graph"
-    assert bench.launch_mode("auto", "lunar_lander") == "eager"
-    assert bench.launch_mode("graph", "lunar_lander") == "graph" and bench.launch_mode("eager", "cartpole") == "eager"
+    assert bench.launch_mode("auto", "lunar_lander", "single_launch") == "graph"
+    assert bench.launch_mode("auto", "lunar_lander", "overlapped") == "eager"
+    assert bench.launch_mode("graph", "lunar_lander", "overlapped") == "graph" and bench.launch_mode("eager", "cartpole") == "eager"
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_is_around():

@@ -43,7 +43,7 @@ def main():
         else:
             lanes64 = active = hbm = 0.0
             per = {}
-            steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_free_kernel" in k] + [1])  # one free-flight launch per step
+            steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_free_kernel" in k or "ll_step_kernel" in k] + [1])  # one step launch (or one free-flight launch) per step
             for k, v in summ.items():
                 if "mgym::ll_" not in k or "pmc" not in v or "f32_flop_per_launch_lanes64" not in v["derived"] or v.get("calls", 0) < 10:
                     continue   # (one-shot kernels — the initial reset of the whole population — are not part of a step)
