@@ -626,6 +626,9 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
     __shared__ ContactLds<BLK> S;
     bool not_reset = false;
     uint32_t overflow = 0u, finished = 0u;
+#ifdef LL_ROLE_MASK   // diagnostic builds (tools/ll_role_time.sh): run only some of the roles, to time them apart (breaks the physics)
+    if (!((LL_ROLE_MASK >> (blockIdx.x < g_contact ? 0 : blockIdx.x < g_contact + g_free ? 1 : 2)) & 1)) return;
+#endif
     if (blockIdx.x < g_contact) {
         ContactList CL;
         CL.list = d.work_list + (uint64_t)L_GENERAL * d.n_pad; CL.back = 0; CL.c0 = d.work_count[L_GENERAL]; CL.c1 = 0; CL.spread = false;
