@@ -162,36 +162,49 @@ __device__ __forceinline__ void ll_free_store_resume(const LLDev& d, uint64_t i,
 // One full Gym::step of a contact-free environment.  FREE_DONE: stepped.  FREE_DECLINED: nothing may be stored, the env
 // must go through the general path from its old state.  FREE_RESUME: the island solve is done and a contact has to be
 // created: store with ll_free_store_resume(moved) and hand the env to the contact kernel.
+// In three pieces — begin, 180 x sweep, finish — so that a lane can take TWO environments through the sweeps side by side
+// (lunar_lander.hip ll_free_pass2: two independent dependent chains in one instruction stream).
 enum { FREE_DECLINED = 0, FREE_DONE = 1, FREE_RESUME = 2 };
-__device__ __forceinline__ int ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
-                                                 float disp0, float disp1, float state[8], float& reward, uint32_t& done, uint32_t& moved) {
+struct FreeSolve { Pos pos[3]; Vel vel[3]; float m_power, s_power; };
+constexpr float kFreeDt = 1.0f / 50.0f;
+
+// wind / engines and b2Island::Solve up to the velocity sweeps; false: FREE_DECLINED (nothing was changed that matters: f, e are the caller's copies)
+__device__ __forceinline__ bool ll_free_begin(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, uint32_t action, float disp0, float disp1, FreeSolve& s) {
     const LLConst& k = LLK(d);
-    moved = 0u;
     if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
         for (int b = 0; b < 3; ++b)
             if ((f.flags >> 9) & (1u << b))
-                if (ll_any_ground_overlap(d, i, f.fat[b])) return FREE_DECLINED;
+                if (ll_any_ground_overlap(d, i, f.fat[b])) return false;
     }
-    float m_power, s_power;
-    ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, m_power, s_power);
+    ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, s.m_power, s.s_power);
 
     // ---- b2Island::Solve, island = {leg1, lander, leg0}, joints in DFS order [joint(leg1), joint(leg0)] ----
-    const float dt = 1.0f / 50.0f, inv_dt = 1.0f / dt, h = dt;
+    const float dt = kFreeDt, inv_dt = 1.0f / dt, h = dt;
     const float dtRatio = ((f.flags & F_STEPPED) ? inv_dt : 0.0f) * dt;
-    Pos pos[3]; Vel vel[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         Body& bd = f.b[b];
         bd.sw.c0 = bd.sw.c; bd.sw.a0 = bd.sw.a;
-        pos[b].c = bd.sw.c; pos[b].a = bd.sw.a;
-        integrate_velocity(bd, b == 0 ? 0 : 1, k, h, vel[b].v, vel[b].w);
+        s.pos[b].c = bd.sw.c; s.pos[b].a = bd.sw.a;
+        integrate_velocity(bd, b == 0 ? 0 : 1, k, h, s.vel[b].v, s.vel[b].w);
     }
-    rj_init_velocity(f.jt[1], 2, k, pos[0].a, pos[2].a, vel[0], vel[2], dtRatio);
-    rj_init_velocity(f.jt[0], 1, k, pos[0].a, pos[1].a, vel[0], vel[1], dtRatio);
-    for (int it = 0; it < 180; ++it) {
-        rj_solve_velocity(f.jt[1], 1, k, vel[0].v, vel[0].w, vel[2].v, vel[2].w, dt, inv_dt);
-        rj_solve_velocity(f.jt[0], 0, k, vel[0].v, vel[0].w, vel[1].v, vel[1].w, dt, inv_dt);
-    }
+    rj_init_velocity(f.jt[1], 2, k, s.pos[0].a, s.pos[2].a, s.vel[0], s.vel[2], dtRatio);
+    rj_init_velocity(f.jt[0], 1, k, s.pos[0].a, s.pos[1].a, s.vel[0], s.vel[1], dtRatio);
+    return true;
+}
+// one of the 180 velocity sweeps: the two joints
+__device__ __forceinline__ void ll_free_sweep(FreeRegs& f, const LLConst& k, FreeSolve& s) {
+    const float dt = kFreeDt, inv_dt = 1.0f / dt;
+    rj_solve_velocity(f.jt[1], 1, k, s.vel[0].v, s.vel[0].w, s.vel[2].v, s.vel[2].w, dt, inv_dt);
+    rj_solve_velocity(f.jt[0], 0, k, s.vel[0].v, s.vel[0].w, s.vel[1].v, s.vel[1].w, dt, inv_dt);
+}
+// positions, sleep, broad phase, observation / reward / termination
+__device__ __forceinline__ int ll_free_finish(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, FreeSolve& s,
+                                              float state[8], float& reward, uint32_t& done, uint32_t& moved) {
+    const LLConst& k = LLK(d);
+    const float h = kFreeDt;
+    moved = 0u;
+    Pos* const pos = s.pos; Vel* const vel = s.vel;
 #pragma unroll
     for (int b = 0; b < 3; ++b) integrate_position(pos[b].c, pos[b].a, vel[b].v, vel[b].w, h);
     bool positionSolved = false;
@@ -234,8 +247,17 @@ __device__ __forceinline__ int ll_free_env_step(const LLDev& d, uint64_t i, Free
     }
     if (create) return FREE_RESUME;
     // SolveTOI: no contacts.  ClearForces; inv_dt0 = inv_dt.
-    ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, m_power, s_power, state, reward, done);
+    ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, s.m_power, s.s_power, state, reward, done);
     return FREE_DONE;
+}
+
+__device__ __forceinline__ int ll_free_env_step(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, uint32_t action,
+                                                 float disp0, float disp1, float state[8], float& reward, uint32_t& done, uint32_t& moved) {
+    FreeSolve s;
+    moved = 0u;
+    if (!ll_free_begin(d, i, f, e, action, disp0, disp1, s)) return FREE_DECLINED;
+    for (int it = 0; it < 180; ++it) ll_free_sweep(f, LLK(d), s);
+    return ll_free_finish(d, i, f, e, tab, s, state, reward, done, moved);
 }
 
 }  // namespace mgym

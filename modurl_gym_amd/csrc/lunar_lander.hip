@@ -206,6 +206,72 @@ __device__ __forceinline__ bool ll_free_pass(const LLDev& d, const LLIo& io, con
     return to_general;
 }
 
+// The same for TWO environments per lane (base + lane and base + 64 + lane), taken through the 180 velocity sweeps side by side: the
+// single-launch step kernel runs one wave per SIMD, and one environment per lane leaves that wave waiting on its own dependent chain
+// (free-flight role alone: 0.59 ms against 0.30 ms for the stand-alone kernel at two waves per SIMD); two independent chains in one
+// instruction stream fill those slots.  Same primitives per environment in the same order: identical results.
+struct FreeLane {
+    uint64_t i; bool run, to_general, to_reset, is_done;
+    FreeRegs f; EnvRegs e; FreeSolve s;
+};
+__device__ __forceinline__ void ll_free_lane_begin(const LLDev& d, const LLIo& io, FreeLane& L, bool& not_reset) {
+    const uint64_t i = L.i;
+    L.run = false; L.to_general = false; L.to_reset = false; L.is_done = false;
+    if (i < d.n && !(d.split && d.env_class[i])) {
+        const uint32_t flags = ST(C_FLAGS);
+        if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+            not_reset = true;
+            if (io.rew) io.rew[i] = 0.0f;
+            if (io.done_out) io.done_out[i] = 0;
+            if (io.trunc_out) io.trunc_out[i] = 0;
+        } else if (!ll_free_eligible(flags)) {
+            L.to_general = true;
+        } else {
+            ll_free_load(d, i, L.f, L.e);
+            float d0, d1;
+            ll_dispersion(d, i, L.e, d0, d1);
+            L.run = ll_free_begin(d, i, L.f, L.e, io.act[i], d0, d1, L.s);
+            L.to_general = !L.run;   // a pending proxy overlaps the ground: the contact path, from the old state
+        }
+    }
+}
+__device__ __forceinline__ void ll_free_lane_finish(const LLDev& d, const LLIo& io, const PolyTab& tab, FreeLane& L) {
+    if (!L.run) return;
+    const uint64_t i = L.i;
+    float state[8], reward; uint32_t done, moved;
+    if (ll_free_finish(d, i, L.f, L.e, tab, L.s, state, reward, done, moved) == FREE_DONE) {
+        ll_free_store(d, i, L.f, L.e);
+        if (io.rew) io.rew[i] = reward;
+        if (io.done_out) io.done_out[i] = (uint8_t)done;
+        if (io.trunc_out) io.trunc_out[i] = 0;  // :1165 truncated: false
+        ll_write_obs(d, io, i, state);
+        L.to_reset = d.auto_reset && done;
+        L.is_done = done != 0u;
+        if (L.to_reset) d.env_class[i] = 2;
+    } else {   // FREE_RESUME: a contact is being created at the end of the step
+        ll_free_store_resume(d, i, L.f, L.e, moved);
+        L.to_general = true;
+    }
+}
+__device__ __forceinline__ void ll_free_pass2(const LLDev& d, const LLIo& io, const PolyTab& tab, uint64_t base, bool& not_reset, uint32_t& finished,
+                                              bool& to_general0, bool& to_general1) {
+    FreeLane A{}, B{};   // (zeroed: a lane without an environment takes harmless numbers through the sweeps)
+    A.i = base + threadIdx.x; B.i = base + 64 + threadIdx.x;
+    ll_free_lane_begin(d, io, A, not_reset);
+    ll_free_lane_begin(d, io, B, not_reset);
+    const LLConst& k = LLK(d);
+    for (int it = 0; it < 180; ++it) {   // one basic block: the two chains interleave
+        ll_free_sweep(A.f, k, A.s);
+        ll_free_sweep(B.f, k, B.s);
+    }
+    ll_free_lane_finish(d, io, tab, A);
+    ll_free_lane_finish(d, io, tab, B);
+    ll_push(d, L_RESET, A.to_reset, (uint32_t)A.i);
+    ll_push(d, L_RESET, B.to_reset, (uint32_t)B.i);
+    finished += (uint32_t)__popcll(__ballot(A.is_done)) + (uint32_t)__popcll(__ballot(B.is_done));
+    to_general0 = A.to_general; to_general1 = B.to_general;
+}
+
 template <int OCC>
 __global__ void __launch_bounds__(kLLBlock, OCC)
 ll_free_kernel(LLDev d, LLIo io) {
@@ -267,7 +333,7 @@ struct ContactLds {
     VConstraint vc[kVcNearLds * BLK];
     uint32_t hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
     uint16_t task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
-    uint32_t late[64];                             // single-launch step: envs this wave's free-flight pass hands to its own contact path
+    uint32_t late[128];                            // single-launch step: envs this wave's free-flight pass hands to its own contact path
 };
 
 // where a wave of the contact path takes its environments from: entry q of a list that is filled from both ends
@@ -612,7 +678,7 @@ ll_reset_kernel(LLDev d, LLIo io, const uint32_t* __restrict__ list, const uint3
 // hipGraph executor or the number of hardware queues could serialise:
 //   [0, g_contact)   the contact path over L_GENERAL (ll_contact_body); dispatched first, so the step's longest dependent chains
 //                    start at once on SIMDs of their own
-//   [.., + g_free)   the free-flight path over everyone else, 64 envs per wave; the few envs a wave has to hand to the contact path
+//   [.., + g_free)   the free-flight path over everyone else, 128 envs per wave (two per lane, side by side through the sweeps); the few envs a wave has to hand to the contact path
 //                    (a contact is created at the end of their step) it takes through ll_contact_body ITSELF, right away, from
 //                    the post-solve state it has just stored (F_RESUME)
 //   [.., + g_prep)   staged resets: the next episode of the envs the previous call's epilogue listed (L_PREP), into the shadow
@@ -641,14 +707,17 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
     } else if (blockIdx.x < g_contact + g_free) {
         const unsigned fb = blockIdx.x - g_contact;
         stage_tab(S.tab, LLK(d));
-        for (uint64_t base = (uint64_t)fb * 64; base < d.n; base += (uint64_t)g_free * 64) {  // wave-uniform trip count
-            const bool to_general = ll_free_pass(d, io, S.tab, base, not_reset, finished);
-            const unsigned long long hand = __ballot(to_general);
-            if (hand != 0ull) {   // (about one wave in five)
-                if (to_general) S.late[__popcll(hand & ((1ull << threadIdx.x) - 1ull))] = (uint32_t)(base + threadIdx.x);
+        for (uint64_t base = (uint64_t)fb * 128; base < d.n; base += (uint64_t)g_free * 128) {  // wave-uniform trip count; two envs per lane
+            bool tg0, tg1;
+            ll_free_pass2(d, io, S.tab, base, not_reset, finished, tg0, tg1);
+            const unsigned long long hand0 = __ballot(tg0), hand1 = __ballot(tg1);
+            if ((hand0 | hand1) != 0ull) {   // (about one wave in three)
+                const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+                if (tg0) S.late[__popcll(hand0 & below)] = (uint32_t)(base + threadIdx.x);
+                if (tg1) S.late[__popcll(hand0) + __popcll(hand1 & below)] = (uint32_t)(base + 64 + threadIdx.x);
                 __syncthreads();
                 ContactList CL;
-                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)__popcll(hand); CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
+                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)(__popcll(hand0) + __popcll(hand1)); CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
                 ll_contact_body<BLK>(d, io, -1, CL, 0, BLK, d.vc_far_late + (uint64_t)fb * BLK, (int)(g_free * BLK), S, not_reset, overflow, finished);
                 __syncthreads();
             }
@@ -968,7 +1037,7 @@ struct LunarLanderEnv final : Env {
         {
             const size_t per_lane = (size_t)(kSolverCap - vc_near_limit);
             // (single-launch step: every wave of the free-flight role may take envs through the contact path itself: a slice per such block)
-            const size_t lanes_main = (size_t)main_contact_grid() * gen_block, lanes_late = (size_t)(single_launch ? grid().x : late_contact_grid()) * 32;
+            const size_t lanes_main = (size_t)main_contact_grid() * gen_block, lanes_late = (size_t)(single_launch ? free2_grid() : late_contact_grid()) * 32;
             MGYM_HIP(hipMalloc(&vc_far_base, per_lane * (lanes_main + lanes_late) * sizeof(VConstraint)));
             dev.vc_far = static_cast<VConstraint*>(vc_far_base);
             dev.vc_far_late = dev.vc_far + per_lane * lanes_main;
@@ -1079,6 +1148,7 @@ struct LunarLanderEnv final : Env {
     }
 
     const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
+    unsigned free2_grid() const { return (unsigned)((n + 127) / 128 ? (n + 127) / 128 : 1); }   // free-flight role of the single-launch kernel: 128 envs per wave
     unsigned classify_grid() const { return (unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256); }
     // The fused order keeps the contact list and class bytes of the NEXT step valid at all times: ll_epilogue_kernel builds them
     // at the end of every step, and whatever else changes the state (reset, set_state, reset_deterministic) rebuilds them here.
@@ -1169,7 +1239,7 @@ struct LunarLanderEnv final : Env {
                     sh.st = static_cast<uint32_t*>(shadow_base); sh.obs = static_cast<float*>(shadow_obs);
                     sh.episode_src = dev.st; sh.prep = 0; sh.split = 0;
                 }
-                const unsigned g_contact = gb, g_free = grid().x, g_prep = stage1 ? 128u : 0u;
+                const unsigned g_contact = gb, g_free = free2_grid(), g_prep = stage1 ? 128u : 0u;
                 hipLaunchKernelGGL(ll_step_kernel<32>, dim3(g_contact + g_free + g_prep), dim3(64), 0, stream, sd, sh, io, g_contact, g_free);
                 LLIo rio1{nullptr, obs_out, nullptr, nullptr, nullptr};
                 if (stage1) {
