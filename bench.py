@@ -105,7 +105,7 @@ def launch_mode(requested, family, launch_order="single_launch"):
     """`--launch auto`: hipGraph replay for every family.  CartPole / MountainCar steps are ~10 us (launch-bound); a LunarLander step is
     two launches on the caller's stream (`launch_order` of mgym_get_info = single_launch), which a graph replays exactly as eager
     launches run (profiles/r03_lunarlander/launch_modes.txt).  Only populations that select the multi-stream order (64-lane contact
-    blocks, from 360 448 envs) stay eager: a graph executor serialises its side branches."""
+    blocks, from 425 984 envs) stay eager: a graph executor serialises its side branches."""
     if requested != "auto":
         return requested
     return "eager" if (family == "lunar_lander" and launch_order != "single_launch") else "graph"

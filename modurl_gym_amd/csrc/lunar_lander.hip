@@ -253,23 +253,27 @@ __device__ __forceinline__ void ll_free_lane_finish(const LLDev& d, const LLIo& 
         L.to_general = true;
     }
 }
-__device__ __forceinline__ void ll_free_pass2(const LLDev& d, const LLIo& io, const PolyTab& tab, uint64_t base, bool& not_reset, uint32_t& finished,
-                                              bool& to_general0, bool& to_general1) {
-    FreeLane A{}, B{};   // (zeroed: a lane without an environment takes harmless numbers through the sweeps)
-    A.i = base + threadIdx.x; B.i = base + 64 + threadIdx.x;
-    ll_free_lane_begin(d, io, A, not_reset);
-    ll_free_lane_begin(d, io, B, not_reset);
+#ifndef LL_FREE_PER_LANE
+#define LL_FREE_PER_LANE 2
+#endif
+constexpr int kFreePerLane = LL_FREE_PER_LANE;   // environments a lane of the single-launch step's free-flight role takes through the sweeps side by side
+__device__ __forceinline__ void ll_free_passN(const LLDev& d, const LLIo& io, const PolyTab& tab, uint64_t base, bool& not_reset, uint32_t& finished,
+                                              bool (&to_general)[kFreePerLane]) {
+    FreeLane L[kFreePerLane] = {};   // (zeroed: a lane without an environment takes harmless numbers through the sweeps)
+#pragma unroll
+    for (int q = 0; q < kFreePerLane; ++q) { L[q].i = base + 64 * q + threadIdx.x; ll_free_lane_begin(d, io, L[q], not_reset); }
     const LLConst& k = LLK(d);
-    for (int it = 0; it < 180; ++it) {   // one basic block: the two chains interleave
-        ll_free_sweep(A.f, k, A.s);
-        ll_free_sweep(B.f, k, B.s);
+    for (int it = 0; it < 180; ++it) {   // one basic block: the chains interleave
+#pragma unroll
+        for (int q = 0; q < kFreePerLane; ++q) ll_free_sweep(L[q].f, k, L[q].s);
     }
-    ll_free_lane_finish(d, io, tab, A);
-    ll_free_lane_finish(d, io, tab, B);
-    ll_push(d, L_RESET, A.to_reset, (uint32_t)A.i);
-    ll_push(d, L_RESET, B.to_reset, (uint32_t)B.i);
-    finished += (uint32_t)__popcll(__ballot(A.is_done)) + (uint32_t)__popcll(__ballot(B.is_done));
-    to_general0 = A.to_general; to_general1 = B.to_general;
+#pragma unroll
+    for (int q = 0; q < kFreePerLane; ++q) {
+        ll_free_lane_finish(d, io, tab, L[q]);
+        ll_push(d, L_RESET, L[q].to_reset, (uint32_t)L[q].i);
+        finished += (uint32_t)__popcll(__ballot(L[q].is_done));
+        to_general[q] = L[q].to_general;
+    }
 }
 
 template <int OCC>
@@ -333,7 +337,7 @@ struct ContactLds {
     VConstraint vc[kVcNearLds * BLK];
     uint32_t hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
     uint16_t task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
-    uint32_t late[128];                            // single-launch step: envs this wave's free-flight pass hands to its own contact path
+    uint32_t late[64 * 4];                         // single-launch step: envs this wave's free-flight pass hands to its own contact path
 };
 
 // where a wave of the contact path takes its environments from: entry q of a list that is filled from both ends
@@ -707,17 +711,24 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
     } else if (blockIdx.x < g_contact + g_free) {
         const unsigned fb = blockIdx.x - g_contact;
         stage_tab(S.tab, LLK(d));
-        for (uint64_t base = (uint64_t)fb * 128; base < d.n; base += (uint64_t)g_free * 128) {  // wave-uniform trip count; two envs per lane
-            bool tg0, tg1;
-            ll_free_pass2(d, io, S.tab, base, not_reset, finished, tg0, tg1);
-            const unsigned long long hand0 = __ballot(tg0), hand1 = __ballot(tg1);
-            if ((hand0 | hand1) != 0ull) {   // (about one wave in three)
+        constexpr int kPerWave = 64 * kFreePerLane;
+        for (uint64_t base = (uint64_t)fb * kPerWave; base < d.n; base += (uint64_t)g_free * kPerWave) {  // wave-uniform trip count
+            bool tg[kFreePerLane];
+            ll_free_passN(d, io, S.tab, base, not_reset, finished, tg);
+            unsigned long long hand[kFreePerLane], any = 0ull;
+#pragma unroll
+            for (int q = 0; q < kFreePerLane; ++q) { hand[q] = __ballot(tg[q]); any |= hand[q]; }
+            if (any != 0ull) {   // (about one wave in three)
                 const unsigned long long below = (1ull << threadIdx.x) - 1ull;
-                if (tg0) S.late[__popcll(hand0 & below)] = (uint32_t)(base + threadIdx.x);
-                if (tg1) S.late[__popcll(hand0) + __popcll(hand1 & below)] = (uint32_t)(base + 64 + threadIdx.x);
+                int at = 0;
+#pragma unroll
+                for (int q = 0; q < kFreePerLane; ++q) {
+                    if (tg[q]) S.late[at + __popcll(hand[q] & below)] = (uint32_t)(base + 64 * q + threadIdx.x);
+                    at += __popcll(hand[q]);
+                }
                 __syncthreads();
                 ContactList CL;
-                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)(__popcll(hand0) + __popcll(hand1)); CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
+                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)at; CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
                 ll_contact_body<BLK>(d, io, -1, CL, 0, BLK, d.vc_far_late + (uint64_t)fb * BLK, (int)(g_free * BLK), S, not_reset, overflow, finished);
                 __syncthreads();
             }
@@ -1002,7 +1013,9 @@ struct LunarLanderEnv final : Env {
         // blocks per CU by LDS — and 64-lane blocks (World record in scratch, working storage in LDS) carry twice
         // the environments per slot.  The overlapped order (contact kernel beside the free-flight kernel, see step()) pays
         // at every size once the blocks are chosen this way.
-        if (gen_block == 0) gen_block = n >= 360448 ? 64 : 32;   // (327 680 envs: 1.42 / 1.60 ms with 32- / 64-lane blocks; 393 216: 1.84 / 1.60)
+        // (round 3, single-launch step with 32-lane blocks against the multi-stream order with 64-lane blocks: 393 216 envs 1.54 / 1.57 ms,
+        // 524 288: 2.04 / 1.68, 1 Mi: 3.81 / 2.86, 2 Mi: 7.38 / 6.11 — profiles/r03_lunarlander/population_block_matrix.txt)
+        if (gen_block == 0) gen_block = n >= 425984 ? 64 : 32;
         if (overlap < 0) overlap = 1;
         obs_dim = 8;
         state_cols = 27;
@@ -1148,7 +1161,7 @@ struct LunarLanderEnv final : Env {
     }
 
     const uint32_t* list_ptr(int which) const { return dev.work_list + (size_t)which * n_pad; }
-    unsigned free2_grid() const { return (unsigned)((n + 127) / 128 ? (n + 127) / 128 : 1); }   // free-flight role of the single-launch kernel: 128 envs per wave
+    unsigned free2_grid() const { const uint64_t per = 64 * kFreePerLane; return (unsigned)((n + per - 1) / per ? (n + per - 1) / per : 1); }   // free-flight role of the single-launch kernel: 64 x kFreePerLane envs per wave
     unsigned classify_grid() const { return (unsigned)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256); }
     // The fused order keeps the contact list and class bytes of the NEXT step valid at all times: ll_epilogue_kernel builds them
     // at the end of every step, and whatever else changes the state (reset, set_state, reset_deterministic) rebuilds them here.
