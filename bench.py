@@ -324,6 +324,7 @@ def main():
     if world > 1 or os.environ.get("MGYM_FORCE_DIST") == "1":  # the env var rehearses the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")   # (only the MGYM_FORCE_DIST=1 rehearsal comes here without a launcher's rendezvous)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     def barrier():
