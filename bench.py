@@ -235,7 +235,7 @@ def lunar_roofline(n, step_s):
     against the 157.3 TFLOP/s f32 vector peak.  The HBM fraction is given for reference."""
     alg = (107 * 4 * 2 + 46) * n   # state words always touched, R + W, + API traffic
     out = {"bound": "valu", "peak": 157.3, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
-           "kernel": "ll_classify_kernel + ll_contact_kernel (beside ll_free_kernel and a second, short ll_contact_kernel launch) + ll_reset_kernel", "avg_step_us": step_s * 1e6,
+           "kernel": "ll_step_kernel<32> (contact path, free-flight path, reset preparation as block roles of one launch) + ll_epilogue_kernel; from 425 984 envs: ll_contact_kernel<64> beside ll_free_kernel + ll_epilogue_kernel", "avg_step_us": step_s * 1e6,
            "hbm_for_reference": {"alg_bytes_per_step": alg, "GBps": alg / step_s / 1e9, "frac": alg / step_s / HBM_PEAK}}
     rec = pmc_record(f"lunar_lander:{n}")
     if rec:
