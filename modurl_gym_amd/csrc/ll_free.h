@@ -103,6 +103,38 @@ __device__ __forceinline__ bool ll_any_ground_overlap(const LLDev& d, uint64_t i
         if (aabb_overlap(box, ll_edge_fat_global(d, i, e))) return true;
     return false;
 }
+// Does the fat AABB of any body in `mask` overlap a ground edge's?  Same answer as ll_any_ground_overlap per body, without its chain
+// of dependent loads (11 edges x 3 bodies, each edge's two heights fetched only after the previous edge's test: ~30 round trips per wave):
+//  * every terrain vertex lies below kTerrainTop — smooth_y = 0.33 (h0 + h1 + h2) with h < H/2 (lunar_lander.rs:753-774), at most
+//    6.6 m, and an edge's fat box reaches polygonRadius + aabbExtension = 0.11 m above its higher vertex — so a body whose box starts
+//    above that overlaps nothing (aabb_overlap would say so for every edge: b.lo.y - a.hi.y > 0) and needs no terrain at all;
+//  * otherwise the 11 heights are fetched together (independent loads, one round trip) and tested from registers.
+constexpr float kTerrainTop = 6.75f;
+__device__ __forceinline__ bool ll_ground_overlap_any_of(const LLDev& d, uint64_t i, const AABB fat[3], uint32_t mask) {
+    uint32_t need = 0u;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+        if (((mask >> b) & 1u) && !(fat[b].lo.y > kTerrainTop)) need |= 1u << b;
+    if (need == 0u) return false;
+    float sm[kEdges];
+#pragma unroll
+    for (int q = 0; q < kEdges; ++q) sm[q] = as_f32(ST(C_SMOOTH + q));
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < kEdges; ++e) {
+        V2 v1, v2;
+        if (e == 0) { v1 = mk(0.0f, 0.0f); v2 = mk(kW, 0.0f); }
+        else { const float cw = kW / 10.0f; v1 = mk(cw * (float)(e - 1), sm[e - 1]); v2 = mk(cw * (float)e, sm[e]); }
+        V2 lower = mk(fmin2(v1.x, v2.x), fmin2(v1.y, v2.y)), upper = mk(fmax2(v1.x, v2.x), fmax2(v1.y, v2.y));
+        AABB a;   // (same arithmetic as edge_fat)
+        a.lo = mk((lower.x - b2_polygonRadius) - b2_aabbExtension, (lower.y - b2_polygonRadius) - b2_aabbExtension);
+        a.hi = mk((upper.x + b2_polygonRadius) + b2_aabbExtension, (upper.y + b2_polygonRadius) + b2_aabbExtension);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if ((need >> b) & 1u) any = any || aabb_overlap(fat[b], a);
+    }
+    return any;
+}
 
 // eligibility from the flag word alone: world exists, all three bodies awake, no cached contacts
 __device__ __forceinline__ bool ll_free_eligible(uint32_t flags) {
@@ -172,9 +204,7 @@ constexpr float kFreeDt = 1.0f / 50.0f;
 __device__ __forceinline__ bool ll_free_begin(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, uint32_t action, float disp0, float disp1, FreeSolve& s) {
     const LLConst& k = LLK(d);
     if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
-        for (int b = 0; b < 3; ++b)
-            if ((f.flags >> 9) & (1u << b))
-                if (ll_any_ground_overlap(d, i, f.fat[b])) return false;
+        if (ll_ground_overlap_any_of(d, i, f.fat, (f.flags >> 9) & 7u)) return false;
     }
     ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, s.m_power, s.s_power);
 
@@ -240,11 +270,9 @@ __device__ __forceinline__ int ll_free_finish(const LLDev& d, uint64_t i, FreeRe
         aabb.lo = mk(fmin2(a1.lo.x, a2.lo.x), fmin2(a1.lo.y, a2.lo.y));
         aabb.hi = mk(fmax2(a1.hi.x, a2.hi.x), fmax2(a1.hi.y, a2.hi.y));
         V2 c1 = 0.5f * (a1.lo + a1.hi), c2 = 0.5f * (a2.lo + a2.hi);
-        if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1)) {
-            moved |= 1u << b;
-            if (ll_any_ground_overlap(d, i, f.fat[b])) create = true;  // a contact would be created: the contact kernel takes over from here
-        }
+        if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1)) moved |= 1u << b;
     }
+    create = ll_ground_overlap_any_of(d, i, f.fat, moved);  // a contact would be created: the contact path takes over from here
     if (create) return FREE_RESUME;
     // SolveTOI: no contacts.  ClearForces; inv_dt0 = inv_dt.
     ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, s.m_power, s.s_power, state, reward, done);

@@ -217,21 +217,27 @@ struct FreeLane {
 __device__ __forceinline__ void ll_free_lane_begin(const LLDev& d, const LLIo& io, FreeLane& L, bool& not_reset) {
     const uint64_t i = L.i;
     L.run = false; L.to_general = false; L.to_reset = false; L.is_done = false;
-    if (i < d.n && !(d.split && d.env_class[i])) {
-        const uint32_t flags = ST(C_FLAGS);
-        if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
-            not_reset = true;
-            if (io.rew) io.rew[i] = 0.0f;
-            if (io.done_out) io.done_out[i] = 0;
-            if (io.trunc_out) io.trunc_out[i] = 0;
-        } else if (!ll_free_eligible(flags)) {
-            L.to_general = true;
-        } else {
-            ll_free_load(d, i, L.f, L.e);
-            float d0, d1;
-            ll_dispersion(d, i, L.e, d0, d1);
-            L.run = ll_free_begin(d, i, L.f, L.e, io.act[i], d0, d1, L.s);
-            L.to_general = !L.run;   // a pending proxy overlaps the ground: the contact path, from the old state
+    if (i < d.n) {
+        // class byte, state columns and action are fetched together, before anything is decided: class byte -> flag word -> state would
+        // be three dependent round trips to memory per environment (the envs of the contact class, one in ten, are fetched for nothing)
+        const uint32_t cls = d.split ? (uint32_t)d.env_class[i] : 0u;
+        const uint32_t action = io.act[i];
+        ll_free_load(d, i, L.f, L.e);
+        const uint32_t flags = L.f.flags;
+        if (cls == 0u) {
+            if (!(flags & F_HAS_WORLD)) {  // assert!(self.lander.is_some(), "You forgot to call reset()") — :920
+                not_reset = true;
+                if (io.rew) io.rew[i] = 0.0f;
+                if (io.done_out) io.done_out[i] = 0;
+                if (io.trunc_out) io.trunc_out[i] = 0;
+            } else if (!ll_free_eligible(flags)) {
+                L.to_general = true;
+            } else {
+                float d0, d1;
+                ll_dispersion(d, i, L.e, d0, d1);
+                L.run = ll_free_begin(d, i, L.f, L.e, action, d0, d1, L.s);
+                L.to_general = !L.run;   // a pending proxy overlaps the ground: the contact path, from the old state
+            }
         }
     }
 }
@@ -263,7 +269,10 @@ __device__ __forceinline__ void ll_free_passN(const LLDev& d, const LLIo& io, co
 #pragma unroll
     for (int q = 0; q < kFreePerLane; ++q) { L[q].i = base + 64 * q + threadIdx.x; ll_free_lane_begin(d, io, L[q], not_reset); }
     const LLConst& k = LLK(d);
-    for (int it = 0; it < 180; ++it) {   // one basic block: the chains interleave
+#ifndef LL_DIAG_FREE_SWEEPS   // diagnostic builds (tools/ll_role_time.hip) cut the sweep count to weigh the loop against the code around it
+#define LL_DIAG_FREE_SWEEPS 180
+#endif
+    for (int it = 0; it < LL_DIAG_FREE_SWEEPS; ++it) {   // one basic block: the chains interleave
 #pragma unroll
         for (int q = 0; q < kFreePerLane; ++q) ll_free_sweep(L[q].f, k, L[q].s);
     }
