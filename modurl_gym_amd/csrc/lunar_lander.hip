@@ -259,8 +259,11 @@ __device__ __forceinline__ void ll_free_lane_finish(const LLDev& d, const LLIo& 
         L.to_general = true;
     }
 }
+// Measured (profiles/r03_lunarlander/tune_free_role_envs_per_lane.txt): two per lane make the role alone 7 % faster (the compiler packs the
+// pair into v_pk ops) but the step no faster, and double the step kernel's counted HBM traffic (1 156 vs 576 MB per launch: the second
+// environment's registers spill around the sweep loop); three and four are slower.  One per lane is the default.
 #ifndef LL_FREE_PER_LANE
-#define LL_FREE_PER_LANE 2
+#define LL_FREE_PER_LANE 1
 #endif
 constexpr int kFreePerLane = LL_FREE_PER_LANE;   // environments a lane of the single-launch step's free-flight role takes through the sweeps side by side
 __device__ __forceinline__ void ll_free_passN(const LLDev& d, const LLIo& io, const PolyTab& tab, uint64_t base, bool& not_reset, uint32_t& finished,
