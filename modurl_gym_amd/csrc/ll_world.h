@@ -890,7 +890,15 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
         st.w[9] = h1 ? as_u32(r1.points[1].normalImpulse) : 0u; st.w[10] = h1 ? as_u32(r1.points[1].tangentImpulse) : 0u;
         return st;
     };
+    // (a one-word digest is compared first: two full 11-word comparisons per sweep were a sixth of a two-constraint sweep's instructions)
+    auto digest = [](const ToiSweepState& st) {
+        uint32_t f = st.w[0];
+#pragma unroll
+        for (int q = 1; q < 11; ++q) f = (f << 3) + (f >> 29) + st.w[q] * (uint32_t)(2 * q + 1);
+        return f;
+    };
     ToiSweepState prev = state_now(), snap = prev;
+    uint32_t prev_f = digest(prev), snap_f = prev_f;
     int done = 0, left = LL_WI_LIMIT(180), snap_at = 0, next_snap = 1;
     LL_DIAG_SWEEP_BEGIN(1);
     while (left > 0) {
@@ -907,14 +915,15 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
 #ifdef LL_TOI_SWEEP_TRACE
             LL_TOI_SWEEP_TRACE(done, cur, cs.count);
 #endif
-            if (toi_state_same(cur, prev)) break;                                                // fixed point
-            if (toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
-            else if (done == next_snap) { snap = cur; snap_at = done; next_snap *= 2; }
+            const uint32_t cur_f = digest(cur);
+            if (cur_f == prev_f && toi_state_same(cur, prev)) break;                                                // fixed point
+            if (cur_f == snap_f && toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
+            else if (done == next_snap) { snap = cur; snap_f = cur_f; snap_at = done; next_snap *= 2; }
             if (can_settle && can_stop && done >= settle_at && cur.w[0] == prev.w[0] && cur.w[1] == prev.w[1] && cur.w[2] == prev.w[2]) {
                 if ((!h0 || toi_velocity_settled_one(r0, vd)) && (!h1 || toi_velocity_settled_one(r1, vd))) break;   // the velocity is final
                 settle_at = 2 * done;
             }
-            prev = cur;
+            prev = cur; prev_f = cur_f;
         }
     }
     LL_DIAG_SWEEP_END(1);

@@ -11,17 +11,20 @@
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
 //
-// One mgym_step (LunarLanderEnv::step, default = the overlapped order):
-//   ll_classify_kernel          contact list + class byte per env, from the flag words
-//   ll_contact_kernel<32|64>    contact path (Collide, island solve, SolveTOI) over that list      caller's stream
-//   ll_free_kernel              register-only step of everyone else, beside it                     helper stream
-//   ll_contact_kernel<32>       the few envs the free-flight kernel declined                       helper stream
-//   ll_apply_select / _copy     fused auto-reset of the finished envs, after the join: the state of       caller's stream
-//                               their next episode was prepared in shadow columns and is copied in
-//   ll_reset_kernel<32>         prepares the NEXT reset of those envs, beside the following step          second helper stream
-// MGYM_LL_OVERLAP=0 runs the step kernels one after the other (free-flight kernel first: it then builds the list);
-// MGYM_LL_STAGED_RESET=0 (and populations from 524 288 envs, and steps captured into a hipGraph) compute a reset when
-// the episode ends (ll_reset_kernel on the caller's stream).
+// One mgym_step (LunarLanderEnv::step).  Up to 425 984 envs per handle — TWO launches on the caller's stream:
+//   ll_step_kernel<32>          the whole step, block roles by index: contact path over the list the previous call's epilogue built
+//                               (Collide, island solve, SolveTOI with the wave's time-of-impact evaluations dealt out over all 64
+//                               lanes), free-flight path over everyone else (register-only; an env that ends its step with a contact
+//                               being created is resumed by the same wave on the contact path, after its island solve), preparation of
+//                               the next resets into shadow columns
+//   ll_epilogue_kernel          fused auto-reset (prepared states copied in), the NEXT step's contact list and class bytes, counters
+//   (+ ll_reset_kernel<32>, ll_general_kernel<64> for resets without a fitting prepared state: only while the host knows of an
+//    event that can have produced one — set_state, dispersion override, unstaged resets)
+// Larger populations (64-lane contact blocks, World records in registers) and MGYM_LL_SINGLE_LAUNCH=0: the multi-stream order of
+// round 2 — ll_contact_kernel on the caller's stream beside ll_free_kernel + a short second contact launch on a helper stream (fork /
+// join by events), then the same epilogue.  MGYM_LL_FUSED_TAIL=0 / MGYM_LL_OVERLAP=0 / MGYM_LL_TOI_ROUNDS / MGYM_LL_BUCKET select the older
+// orders (counter memsets + ll_classify_kernel per step, select / copy launches, sequential kernels, follow-up TOI launches): profiling.
+// MGYM_LL_STAGED_RESET=0 (and populations from 524 288 envs) compute a reset when the episode ends instead of preparing it ahead.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
