@@ -746,13 +746,16 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     k.motorSpeed[0] = k_in.motorSpeed[0]; k.motorSpeed[1] = k_in.motorSpeed[1];
     k.maxMotorTorque = k_in.maxMotorTorque;
     const int n_cs = cs.count;
-    constexpr int kReg = 4;  // constraints held in registers (the kernel runs at one wave per SIMD: 512 VGPRs per lane)
+#ifndef LL_ISLAND_REGS
+#define LL_ISLAND_REGS 4
+#endif
+    constexpr int kReg = LL_ISLAND_REGS;  // constraints held in registers (2..4; the kernel runs at one wave per SIMD: 512 VGPRs per lane)
     VConstraint r0, r1, r2, r3;
     int rb0 = -1, rb1 = -1, rb2 = -1, rb3 = -1;
     if (cs.count > 0) { r0 = cs_vc(cs, 0); rb0 = r0.indexB; }
     if (cs.count > 1) { r1 = cs_vc(cs, 1); rb1 = r1.indexB; }
-    if (cs.count > 2) { r2 = cs_vc(cs, 2); rb2 = r2.indexB; }   // (the third and fourth may live in the far workspace)
-    if (cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }
+    if (kReg > 2 && cs.count > 2) { r2 = cs_vc(cs, 2); rb2 = r2.indexB; }   // (the third and fourth may live in the far workspace)
+    if (kReg > 3 && cs.count > 3) { r3 = cs_vc(cs, 3); rb3 = r3.indexB; }
     LL_DIAG_SWEEP_BEGIN(0);
     for (int it = 0; it < LL_WI_LIMIT(180); ++it) {
         if (leg1_first) {
@@ -764,8 +767,8 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
         }
         if (rb0 >= 0) cs_solve_one_on(r0, rb0, vel);
         if (rb1 >= 0) cs_solve_one_on(r1, rb1, vel);
-        if (rb2 >= 0) cs_solve_one_on(r2, rb2, vel);
-        if (rb3 >= 0) cs_solve_one_on(r3, rb3, vel);
+        if (kReg > 2 && rb2 >= 0) cs_solve_one_on(r2, rb2, vel);
+        if (kReg > 3 && rb3 >= 0) cs_solve_one_on(r3, rb3, vel);
         if (n_cs > kReg) {
             for (int q = 0; q < nb; ++q) {  // remaining contacts, grouped by body in DFS order
                 const int c0 = cstart[q] > kReg ? cstart[q] : kReg, c1 = cstart[q + 1] < n_cs ? cstart[q + 1] : n_cs;
@@ -788,8 +791,8 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
     LL_DIAG_SWEEP_END(0);
     if (rb0 >= 0) cs_vc(cs, 0) = r0;
     if (rb1 >= 0) cs_vc(cs, 1) = r1;
-    if (rb2 >= 0) cs_vc(cs, 2) = r2;
-    if (rb3 >= 0) cs_vc(cs, 3) = r3;
+    if (kReg > 2 && rb2 >= 0) cs_vc(cs, 2) = r2;
+    if (kReg > 3 && rb3 >= 0) cs_vc(cs, 3) = r3;
     J0_io = J0; J1_io = J1; vel_io = vel;
 }
 
