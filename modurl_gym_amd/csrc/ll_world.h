@@ -68,6 +68,7 @@ struct World {
     float gA;               // b2World::SolveTOI: alpha0 of the static ground's sweep (its c0/a0 never move; only alpha0 ratchets)
     uint32_t pending;       // bits 0..2: proxy of body i waits in the move buffer (test seam only)
     bool newContacts, stepped_once;
+    int n_collide;          // Collide: length of the contact list between collide_list and collide_apply
     bool resume;            // the free-flight kernel has done this step's island solve; continue at FindNewContacts (ll_env.h F_RESUME)
     bool game_over, legs[2];  // ContactDetector (lunar_lander.rs:139-205)
     uint32_t overflow;        // capacity exhausted, reported through the sticky status: bit 0 contact cache (kSlots pairs), bit 1 island solver (kSolverCap touching contacts)
@@ -239,25 +240,79 @@ LLD int contact_order(const World& w, I* order) {
     return n;
 }
 
-LLD void collide(World& w, const PolyTab& tab) {  // b2ContactManager::Collide
+// b2ContactManager::Collide in three pieces, so that the kernels can run the manifold refreshes of a whole wave side by side (as SolveTOI's
+// evaluations): the list walk is split into (1) collide_list — which contacts go away (fat boxes stopped overlapping) and which are
+// refreshed, in list order; (2) collide_refresh — b2Contact::Update of ONE contact without its callbacks: the new manifold
+// (b2CollideEdgeAndPolygon, the expensive part), the warm-start impulses matched by feature id, the key bits; a function of the contact, its
+// body's transform and its edge only; (3) collide_apply — the wake-ups and ContactDetector callbacks of (1) and (2), in list order.
+// Same operations as the single walk: a contact only ever wakes its OWN body and is skipped when that body sleeps, so whether a contact is
+// visited does not depend on the contacts before it, and the callbacks (which set and clear the same leg flags) keep their order.
+enum : uint32_t { CK_WAS_TOUCHING = 1u << 19, CK_DESTROY = 1u << 20, CK_REFRESH = 1u << 21 };   // (within Collide only)
+LLD int collide_list(World& w) {   // -> number of refreshes; their slots in w.t->idx[1], the whole list in w.t->idx[0] with its length in w.n_collide
     uint8_t* const order = (uint8_t*)w.t->idx[0];
-    int n = contact_order(w, order);
+    uint8_t* const refresh = (uint8_t*)w.t->idx[1];
+    const int n = contact_order(w, order);
+    int n_ref = 0;
     for (int k = 0; k < n; ++k) {
         const uint32_t key = ct_key(w.cs, order[k]);
         const int body = ck_body(key), edge = ck_edge(key);
         if (!w.b[body].awake) continue;
-        if (!aabb_overlap(edge_fat(w, edge), w.fat[body])) {  // b2ContactManager::Destroy
+        if (!aabb_overlap(edge_fat(w, edge), w.fat[body])) { ct_set_key(w.cs, order[k], key | CK_DESTROY); continue; }  // b2ContactManager::Destroy, in collide_apply
+        if (LL_WHATIF(w, WI_NO_COLLIDE_UPDATE)) continue;
+        ct_set_key(w.cs, order[k], key | CK_REFRESH);
+        refresh[n_ref++] = order[k];
+    }
+    w.n_collide = n;
+    return n_ref;
+}
+// (`wo` may be another lane's World record, in LDS; `poly_tmp`: 2 * kMaxPoly vectors of the EXECUTING lane)
+LLD void collide_refresh(World& wo, const PolyTab& tab, int slot, V2* poly_tmp) {
+    Contact c = ct_get(wo.cs, slot);
+    const Manifold oldManifold = c.m;
+    c.enabled = true;
+    const bool wasTouching = c.touching;
+    V2 v1, v2;
+    edge_verts(wo, c.edge, v1, v2);
+    collide_edge_polygon(c.m, v1, v2, tab, poly_of(c.body), wo.b[c.body].xf, poly_tmp);
+    for (int i = 0; i < c.m.pointCount; ++i) {
+        MPoint& mp2 = c.m.points[i];
+        mp2.normalImpulse = 0.0f;
+        mp2.tangentImpulse = 0.0f;
+        for (int j = 0; j < oldManifold.pointCount; ++j) {
+            const MPoint& mp1 = oldManifold.points[j];
+            if (cf_equal(mp1.id, mp2.id)) {
+                mp2.normalImpulse = mp1.normalImpulse;
+                mp2.tangentImpulse = mp1.tangentImpulse;
+                break;
+            }
+        }
+    }
+    c.touching = c.m.pointCount > 0;
+    ct_put(wo.cs, slot, c);
+    ct_set_key(wo.cs, slot, ct_key(wo.cs, slot) | CK_REFRESH | (wasTouching ? CK_WAS_TOUCHING : 0u));   // (ct_put encodes the persistent bits)
+}
+LLD void collide_apply(World& w) {
+    const uint8_t* const order = (const uint8_t*)w.t->idx[0];
+    for (int k = 0; k < w.n_collide; ++k) {
+        const uint32_t key = ct_key(w.cs, order[k]);
+        const int body = ck_body(key);
+        if (key & CK_DESTROY) {
             if (key & CK_TOUCHING) on_end(w, body);
             if (((key >> 11) & 3u) > 0u) body_set_awake(w.b[body], true);
             ct_set_key(w.cs, order[k], 0u);
-            continue;
+        } else if (key & CK_REFRESH) {
+            const bool was = key & CK_WAS_TOUCHING, now = key & CK_TOUCHING;
+            if (now != was) body_set_awake(w.b[body], true);
+            if (!was && now) on_begin(w, body);
+            if (was && !now) on_end(w, body);
+            ct_set_key(w.cs, order[k], key & ~(CK_REFRESH | CK_WAS_TOUCHING));
         }
-        if (LL_WHATIF(w, WI_NO_COLLIDE_UPDATE)) continue;
-        Contact& c = *(Contact*)&w.t->tmp;
-        c = ct_get(w.cs, order[k]);
-        contact_update(w, tab, c);
-        ct_put(w.cs, order[k], c);
     }
+}
+LLD void collide(World& w, const PolyTab& tab) {  // one lane runs every piece itself (host check, the kernels that do not deal the refreshes out)
+    const int n_ref = collide_list(w);
+    for (int j = 0; j < n_ref; ++j) collide_refresh(w, tab, ((const uint8_t*)w.t->idx[1])[j], (V2*)w.t->poly_tmp);
+    collide_apply(w);
 }
 
 // ---- contact solver over a list of slots --------------------------------------------------------------
@@ -1337,6 +1392,29 @@ LLD void world_step_begin(World& w, const PolyTab& tab, const LLConst& k, const 
     LL_STAMP(0);
     collide(w, tab);
     LL_STAMP(1);
+    solve_island(w, tab, k, mem, dt, inv_dt, dtRatio);
+    LL_STAMP(6);
+}
+// the same in the pieces the contact kernel deals out over its wave: world_step_pre (-> number of manifold refreshes, listed),
+// collide_refresh per listed contact (any lane), world_step_island
+LLD int world_step_pre(World& w) {
+    if (w.newContacts) {
+        int order[3], n = 0;
+        for (int i = 0; i < 3; ++i)
+            if (w.pending & (1u << i)) order[n++] = i;
+        find_new_contacts(w, order, n);
+        w.pending = 0;
+        w.newContacts = false;
+    }
+    LL_STAMP(0);
+    return collide_list(w);
+}
+LLD void world_step_island(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem) {
+    collide_apply(w);
+    LL_STAMP(1);
+    const float dt = kStepDt;
+    const float inv_dt = 1.0f / dt;
+    const float dtRatio = (w.stepped_once ? inv_dt : 0.0f) * dt;
     solve_island(w, tab, k, mem, dt, inv_dt, dtRatio);
     LL_STAMP(6);
 }

@@ -391,6 +391,8 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
         bool stepping = false;      // this lane is inside world.step
+        bool islanding = false;     // ... between Collide's list walk and the island solve
+        int n_refresh = 0;          // manifold refreshes this lane has listed
         bool step_complete = true;  // ... and has finished it (false only with toi_budget >= 0: profiling)
         World w_local;
         World& w = kWorldLds ? S.world[kWorldLds ? own : 0] : w_local;
@@ -413,10 +415,36 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
                     float d0, d1, m_power, s_power;
                     ll_dispersion(d, i, e, d0, d1);
                     ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
-                    world_step_begin(w, tab, LLK(d), mem);                                                     // world.step up to SolveTOI, :1066
+                    if constexpr (kWorldLds) { n_refresh = world_step_pre(w); islanding = true; }              // world.step, :1066: Collide's list walk
+                    else world_step_begin(w, tab, LLK(d), mem);                                                // ... or everything up to SolveTOI
                 }
                 stepping = true;
             }
+        }
+        // b2ContactManager::Collide: the manifold refreshes of the wave's cached contacts (b2CollideEdgeAndPolygon + warm-start matching,
+        // ~10 k cycles each, up to ~7 per lane) are dealt out over all 64 lanes like the time-of-impact evaluations below; the callbacks
+        // they imply are applied by the owner afterwards, in list order (ll_world.h collide_list / _refresh / _apply)
+        if constexpr (kWorldLds) {
+            int incl = n_refresh;
+            for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
+            const int n_tasks = __shfl(incl, 63);
+            if (n_tasks > 0) {   // wave-uniform
+                const int offs = incl - n_refresh;
+                for (int j = 0; j < n_refresh; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
+                __syncthreads();
+                // the executing lane's polygon buffer: its own working record, or (helper lanes) a piece of the constraint columns,
+                // which nothing uses before the island solver is set up
+                constexpr int kHelpRoom = (int)(sizeof(S.vc) / (2 * kMaxPoly * sizeof(V2)));
+                constexpr int kExec = BLK + ((kThreads - BLK) < kHelpRoom ? (kThreads - BLK) : kHelpRoom);   // lanes that have a polygon buffer (all 64 for 32-lane blocks)
+                V2* const poly_tmp = env_lane ? (V2*)((LL_LDS WorldTmp*)S.tmp + own)->poly_tmp : (V2*)S.vc + (size_t)(threadIdx.x - BLK) * (2 * kMaxPoly);
+                if ((int)threadIdx.x < kExec)
+                    for (int t = (int)threadIdx.x; t < n_tasks; t += kExec) {
+                        const uint32_t task = S.task[t];
+                        collide_refresh(S.world[task >> 4], tab, (int)(task & 15u), poly_tmp);
+                    }
+                __syncthreads();
+            }
+            if (islanding) world_step_island(w, tab, LLK(d), mem);   // the callbacks of Collide, then b2World::Solve
         }
         // b2World::SolveTOI.  With the World records in LDS the wave runs its passes in lock step and DEALS THE
         // TIME-OF-IMPACT EVALUATIONS OF A PASS OUT OVER ALL 64 LANES: an evaluation (GJK + root finder: the longest
