@@ -13,26 +13,36 @@
 namespace mgym {
 using namespace ll;
 
+// State words of one environment.  LL_RECORD_LAYOUT 1 (default): one RECORD of kRec words per environment, 128-byte aligned, the words the
+// free-flight role touches in its first two cache lines (0-55), terrain and contact cache behind them — every role reads and writes whole
+// lines of its own environments, however scattered those are (the contact role's list holds ~9 % of the population: with one COLUMN per
+// word each of its 4-byte accesses moved a 64-byte line, ~350 MB of the 612 MB counted per step of 262 144 envs).  0: the column layout
+// of rounds 1-3 ([word][n_pad]), kept for A/B runs.
+#ifndef LL_RECORD_LAYOUT
+#define LL_RECORD_LAYOUT 1
+#endif
 enum Col : int {
     C_BODY = 0,        // + 9*i : PX PY CX CY A VX VY W SLEEP
     C_JOINT = 27,      // + 5*j : IMPX IMPY MOTOR LOWER UPPER
     C_FAT = 37,        // + 4*i : lo.x lo.y hi.x hi.y
-    C_SMOOTH = 49,     // 11
-    C_PREV = 60,
-    C_FLAGS = 61,
-    C_WIND = 62,
-    C_TORQUE = 63,
-    C_STEP = 64,
-    C_EPISODE = 65,
-    C_SEQ = 66,
-    C_CONTACT = 67,    // + 16*s : KEY SEQ LNX LNY LPX LPY P0X P0Y P0N P0T P1X P1Y P1N P1T IDS TOI
+    C_PREV = 49,
+    C_FLAGS = 50,
+    C_WIND = 51,
+    C_TORQUE = 52,
+    C_STEP = 53,
+    C_EPISODE = 54,
+    C_SEQ = 55,        // (56-63 unused: the third line starts with the terrain)
+    C_SMOOTH = 64,     // 11 (75-79 unused)
+    C_CONTACT = 80,    // + 16*s : KEY SEQ LNX LNY LPX LPY P0X P0Y P0N P0T P1X P1Y P1N P1T IDS TOI
                        //   KEY bits: 0 exists, 1 touching, 2 enabled, 3-4 body, 5-8 edge, 9-10 manifold type, 11-12 pointCount,
                        //             13 toiFlag, 14-17 toiCount (the last two and TOI only matter inside a step, see C_MID)
                        //   IDS = contact-feature ids of both manifold points, 16 bits each
-    C_MID = 67 + 16 * kSlots,  // state of an unfinished SolveTOI between the launches of one step (solve_toi_part):
+    C_MID = C_CONTACT + 16 * kSlots,  // state of an unfinished SolveTOI between the launches of one step (solve_toi_part):
                                //   + 4*i : sweep c0.x c0.y a0 alpha0 of body i; + 12 : gA
     C_COUNT = C_MID + 13
 };
+constexpr int kRec = 288;   // words per record (9 lines of 128 bytes)
+static_assert(C_COUNT <= kRec, "record too small");
 
 enum Flag : uint32_t {
     F_AWAKE0 = 1u << 0, F_GAME_OVER = 1u << 3, F_LEG0 = 1u << 4, F_LEG1 = 1u << 5, F_HAS_WORLD = 1u << 6,
@@ -44,7 +54,7 @@ enum Flag : uint32_t {
 };
 
 struct LLDev {
-    uint32_t* st;       // state columns [C_COUNT][n_pad]
+    uint32_t* st;       // state: records [n_pad][kRec] (LL_RECORD_LAYOUT 0: columns [C_COUNT][n_pad])
     float* obs;         // engine-owned observation [8][n_pad]
     const float* disp;  // dispersion override [2][n] or nullptr
     uint64_t n, n_pad, seed, env_id_base;
@@ -87,7 +97,16 @@ struct EnvRegs {  // LunarLanderV3 fields beside the world (lunar_lander.rs:232-
     bool has_world, deterministic;
 };
 
-#define ST(col) d.st[(uint64_t)(col) * d.n_pad + i]
+#if LL_RECORD_LAYOUT
+#define ST_AT(base, col) (base)[(uint64_t)i * kRec + (uint64_t)(col)]
+#define LL_CT_STRIDE(d) 1u
+constexpr uint64_t ll_state_words(uint64_t n_pad) { return (uint64_t)kRec * n_pad; }
+#else
+#define ST_AT(base, col) (base)[(uint64_t)(col) * d.n_pad + i]
+#define LL_CT_STRIDE(d) (d).n_pad
+constexpr uint64_t ll_state_words(uint64_t n_pad) { return (uint64_t)C_COUNT * n_pad; }
+#endif
+#define ST(col) ST_AT(d.st, col)
 #define LLK(d) (*(d).kd)
 
 // mid = true: continue an unfinished SolveTOI (the env was stored by ll_store(..., mid = true) earlier in this step)
@@ -137,7 +156,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     w.whatif = d.whatif;
 #endif
     // the contact cache: manifold words in place, KEY / SEQ / TOI staged in `hot` for the step (ll_b2.h)
-    w.cs.p = &ST(C_CONTACT); w.cs.stride = d.n_pad; w.cs.hot = hot;
+    w.cs.p = &ST(C_CONTACT); w.cs.stride = LL_CT_STRIDE(d); w.cs.hot = hot;
     for (int s = 0; s < kSlots; ++s) {
         ct_set_key(w.cs, s, ST(C_CONTACT + 16 * s + 0));
         ct_set_seq(w.cs, s, ST(C_CONTACT + 16 * s + 1));

@@ -3,11 +3,13 @@
 // Replaces the bodies of `impl Gym for LunarLanderV3` (reference src/box_2d/lunar_lander.rs: reset
 // :727-917, step :919-1167) and the box2d-rs world it drives (ll_b2.h / ll_world.h restate Box2D).
 //
-// Data layout in HBM (engine-owned SoA, column stride n_pad words; 259 state columns + 8 observation
-// columns, ~1 KB per env of which ~0.45 KB are touched in free flight; see enum Col):
-//   3 bodies x {xf.p, sweep.c, angle, v, w, sleepTime}; 2 joints x {impulse.xy, motor, lower, upper};
-//   3 fat AABBs; terrain smooth_y[11]; prev_shaping; flag word; wind/torque indices; step/episode
-//   counters (Philox slots); 12 contact-cache slots x 16 words (worked on in place, KEY/SEQ/TOI staged in LDS: ll_b2.h).
+// Data layout in HBM (engine-owned): one RECORD of 288 words (9 lines of 128 bytes) per environment — see enum Col, ll_env.h —
+// plus 8 observation columns [8][n_pad].  Lines 0-1: what a free-flight step touches (3 bodies x {xf.p, sweep.c, angle, v, w,
+// sleepTime}; 2 joints x {impulse.xy, motor, lower, upper}; 3 fat AABBs; prev_shaping; flag word; wind/torque indices; step/episode
+// counters (Philox slots)); line 2: terrain smooth_y[11]; then 12 contact-cache slots x 16 words (worked on in place, KEY/SEQ/TOI staged
+// in LDS: ll_b2.h) and the 13 words of an unfinished SolveTOI.  Every role moves whole lines of ITS environments: the contact role's
+// list is a scattered ~9 % of the population, and with one column per word (rounds 1-3) each of its 4-byte accesses moved a 64-byte
+// line — 568 MB counted per step of 262 144 envs against 274 MB with records (profiles/r03_lunarlander/ab_records.txt).
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
 //
@@ -16,7 +18,7 @@
 //                               (Collide, island solve, SolveTOI with the wave's time-of-impact evaluations dealt out over all 64
 //                               lanes), free-flight path over everyone else (register-only; an env that ends its step with a contact
 //                               being created is resumed by the same wave on the contact path, after its island solve), preparation of
-//                               the next resets into shadow columns
+//                               the next resets into shadow records
 //   ll_epilogue_kernel          fused auto-reset (prepared states copied in), the NEXT step's contact list and class bytes, counters
 //   (+ ll_reset_kernel<32>, ll_general_kernel<64> for resets without a fitting prepared state: only while the host knows of an
 //    event that can have produced one — set_state, dispersion override, unstaged resets)
@@ -681,7 +683,7 @@ __device__ __forceinline__ void ll_reset_pass(const LLDev& d, const LLIo& io, co
     bool slow = false;
     if (q < total) {
         if (list) i = list[q];
-        if (d.episode_src) ST(C_EPISODE) = d.episode_src[(uint64_t)C_EPISODE * d.n_pad + i];  // preparing in the shadow columns: the episode to draw is the live one
+        if (d.episode_src) ST(C_EPISODE) = ST_AT(d.episode_src, C_EPISODE);  // preparing in the shadow columns: the episode to draw is the live one
         V2 force; float torque;
         {
             World w; EnvRegs e;
@@ -815,7 +817,7 @@ ll_apply_select_kernel(LLDev d, const uint32_t* __restrict__ shadow) {
         bool fits = false, direct = false;
         if (q < total) {
             i = list[q];
-            fits = shadow[(uint64_t)C_EPISODE * d.n_pad + i] == ST(C_EPISODE) + 1u;
+            fits = ST_AT(shadow, C_EPISODE) == ST(C_EPISODE) + 1u;
             direct = !fits;
         }
         ll_push_block(d, L_PREP, fits, (uint32_t)i, s_cnt);
@@ -830,7 +832,7 @@ ll_apply_copy_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* 
     const int t = threadIdx.x;
     for (uint64_t q = blockIdx.x; q < total; q += gridDim.x) {
         const uint64_t i = list[q];
-        if (t < C_CONTACT) ST(t) = shadow[(uint64_t)t * d.n_pad + i];
+        if (t < C_CONTACT) ST(t) = ST_AT(shadow, t);
         else if (t < C_CONTACT + kSlots) ST(C_CONTACT + 16 * (t - C_CONTACT)) = 0u;  // a fresh world has no contacts
         else if (t < C_CONTACT + kSlots + 8) {
             const int k = t - C_CONTACT - kSlots;
@@ -865,7 +867,7 @@ ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __
             bool fits = false;
             if (valid) {
                 i = list[idx];
-                fits = shadow[(uint64_t)C_EPISODE * d.n_pad + i] == ST(C_EPISODE) + 1u;
+                fits = ST_AT(shadow, C_EPISODE) == ST(C_EPISODE) + 1u;
             }
             ll_push_block(d, L_PREP, fits, i, s_cnt);
             ll_push_block(d, L_RESET_DIRECT, valid && !fits, i, s_cnt);
@@ -879,7 +881,7 @@ ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __
                 const uint64_t i = s_ent[k];
                 if (i == 0xffffffffu) continue;
                 for (int t = lane; t < C_CONTACT + kSlots + 8; t += 64) {
-                    if (t < C_CONTACT) ST(t) = shadow[(uint64_t)t * d.n_pad + i];
+                    if (t < C_CONTACT) ST(t) = ST_AT(shadow, t);
                     else if (t < C_CONTACT + kSlots) ST(C_CONTACT + 16 * (t - C_CONTACT)) = 0u;  // a fresh world has no contacts
                     else {
                         const int k8 = t - C_CONTACT - kSlots;
@@ -1062,8 +1064,8 @@ struct LunarLanderEnv final : Env {
         if (overlap < 0) overlap = 1;
         obs_dim = 8;
         state_cols = 27;
-        MGYM_HIP(hipMalloc(&base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
-        MGYM_HIP(hipMemsetAsync(base, 0, (size_t)C_COUNT * n_pad * sizeof(uint32_t), stream));  // has_world = false
+        MGYM_HIP(hipMalloc(&base, (size_t)ll_state_words(n_pad) * sizeof(uint32_t)));
+        MGYM_HIP(hipMemsetAsync(base, 0, (size_t)ll_state_words(n_pad) * sizeof(uint32_t), stream));  // has_world = false
         MGYM_HIP(hipMalloc(&obs_base, (size_t)8 * n_pad * sizeof(float)));
         MGYM_HIP(hipMemsetAsync(obs_base, 0, (size_t)8 * n_pad * sizeof(float), stream));
         dev.st = static_cast<uint32_t*>(base);
@@ -1116,8 +1118,8 @@ struct LunarLanderEnv final : Env {
         // extra launches: 524 288 envs 1.86 -> 1.83, 1 Mi envs 3.53 -> 3.84; MGYM_LL_STAGED_RESET=2 forces it on)
         staged = (staged == 2 || (staged == 1 && n < 524288)) && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
         if (staged) {
-            MGYM_HIP(hipMalloc(&shadow_base, (size_t)C_COUNT * n_pad * sizeof(uint32_t)));
-            MGYM_HIP(hipMemsetAsync(shadow_base, 0, (size_t)C_COUNT * n_pad * sizeof(uint32_t), stream));
+            MGYM_HIP(hipMalloc(&shadow_base, (size_t)ll_state_words(n_pad) * sizeof(uint32_t)));
+            MGYM_HIP(hipMemsetAsync(shadow_base, 0, (size_t)ll_state_words(n_pad) * sizeof(uint32_t), stream));
             MGYM_HIP(hipMalloc(&shadow_obs, (size_t)8 * n_pad * sizeof(float)));
             MGYM_HIP(hipMemsetAsync(shadow_obs, 0, (size_t)8 * n_pad * sizeof(float), stream));
             int lo = 0, hi = 0;
@@ -1146,6 +1148,14 @@ struct LunarLanderEnv final : Env {
     // Preparation state.  prep_due: L_PREP may hold envs (put there by an epilogue) that no preparation launch has been issued for;
     // ev_prep_valid: ev_prep is a real record on `stream` behind that epilogue (a record made while capturing is not);
     // prep_pending: a launch is on aux2 that `stream` has not waited for yet (never true between calls).
+    // prepared states no longer fit: episode 0 in every shadow record never equals a live counter + 1
+    hipError_t clear_shadow_episodes() {
+#if LL_RECORD_LAYOUT
+        return hipMemset2DAsync(static_cast<uint32_t*>(shadow_base) + C_EPISODE, (size_t)kRec * sizeof(uint32_t), 0, sizeof(uint32_t), n_pad, stream);
+#else
+        return hipMemsetAsync(static_cast<uint32_t*>(shadow_base) + (size_t)C_EPISODE * n_pad, 0, n_pad * sizeof(uint32_t), stream);
+#endif
+    }
     // `stream` waits for the preparation work put on aux2 so far: before anything appends to L_PREP or reads the shadow columns
     int join_helpers() override {
         if (prep_due && !capturing()) {   // marked by the last step, no step followed
@@ -1443,7 +1453,7 @@ struct LunarLanderEnv final : Env {
         if (staged) {  // states prepared under the other dispersion source no longer fit: episode 0 never equals a live counter + 1
             int st = join_helpers();
             if (st != MGYM_OK) return st;
-            MGYM_HIP(hipMemsetAsync(static_cast<uint32_t*>(shadow_base) + (size_t)C_EPISODE * n_pad, 0, n_pad * sizeof(uint32_t), stream));
+            MGYM_HIP(clear_shadow_episodes());
         }
         dev.disp = disp;
         return MGYM_OK;

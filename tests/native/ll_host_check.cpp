@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     LLDev d;
     memset(&d, 0, sizeof d);
     d.n = n; d.n_pad = (n + 1023) / 1024 * 1024; d.seed = seed; d.env_id_base = 0;
-    std::vector<uint32_t> st((size_t)C_COUNT * d.n_pad, 0u);
+    std::vector<uint32_t> st((size_t)ll_state_words(d.n_pad), 0u);
     std::vector<float> obsbuf((size_t)8 * d.n_pad, 0.0f);
     d.st = st.data(); d.obs = obsbuf.data();
     ll_make_const(d.k, -10.0f, wind, 15.0f, 1.5f);
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
             float state[8], reward, d0, d1; uint32_t done;
             // same dispatch as ll_free_kernel / ll_general_kernel: fast path when eligible and it accepts
             bool fast = false;
-            if (ll_free_eligible(d.st[(uint64_t)C_FLAGS * d.n_pad + i])) {
+            if (ll_free_eligible(ST(C_FLAGS))) {
                 FreeRegs f; EnvRegs e;
                 ll_free_load(d, i, f, e);
                 ll_dispersion(d, i, e, d0, d1);
@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
                 World w; EnvRegs e;
                 w.t = &h_tmp;
 #ifdef LL_HOST_STATS
-                const uint32_t flags0 = d.st[(uint64_t)C_FLAGS * d.n_pad + i];
+                const uint32_t flags0 = ST(C_FLAGS);
                 const int touching0 = (flags0 & F_TOUCHING) ? 1 : 0, ncont0 = (int)((flags0 >> F_NCONTACT_SHIFT) & 15u);
 #endif
                 ll_load(d, i, w, e, hot);

@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     uint32_t* act; float* rew; uint8_t *dn, *tr;
     CK(hipMalloc((void**)&act, 16 * n * 4)); CK(hipMalloc((void**)&rew, n * 4)); CK(hipMalloc((void**)&dn, n)); CK(hipMalloc((void**)&tr, n));
     { std::vector<uint32_t> h(16 * n); uint32_t s = 12345; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (s >> 16) & 3; } CK(hipMemcpy(act, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
-    const size_t st_bytes = (size_t)C_COUNT * env.n_pad * 4, wc_bytes = (size_t)(L_LISTS * env.n_pad + 64) * 4;
+    const size_t st_bytes = (size_t)ll_state_words(env.n_pad) * 4, wc_bytes = (size_t)(L_LISTS * env.n_pad + 64) * 4;
     std::vector<char> st(st_bytes), sh(st_bytes), wc(wc_bytes), cls(env.n_pad);
     const char* path = "/tmp/ll_role_state.bin";
     FILE* f = fopen(path, "rb");

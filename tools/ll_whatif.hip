@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     env.reset(nullptr, nullptr, true, nullptr);
     for (int t = 0; t < warm; ++t) env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);
     CK(hipStreamSynchronize(env.stream));
-    const size_t st_bytes = (size_t)C_COUNT * env.n_pad * 4;
+    const size_t st_bytes = (size_t)ll_state_words(env.n_pad) * 4;
     void* backup; CK(hipMalloc(&backup, st_bytes));
     CK(hipMemcpy(backup, env.dev.st, st_bytes, hipMemcpyDeviceToDevice));
     struct V { uint32_t mask; const char* what; };
