@@ -26,7 +26,7 @@
 // round 2 — ll_contact_kernel on the caller's stream beside ll_free_kernel + a short second contact launch on a helper stream (fork /
 // join by events), then the same epilogue.  MGYM_LL_FUSED_TAIL=0 / MGYM_LL_OVERLAP=0 / MGYM_LL_TOI_ROUNDS / MGYM_LL_BUCKET select the older
 // orders (counter memsets + ll_classify_kernel per step, select / copy launches, sequential kernels, follow-up TOI launches): profiling.
-// MGYM_LL_STAGED_RESET=0 (and populations from 524 288 envs) compute a reset when the episode ends instead of preparing it ahead.
+// MGYM_LL_STAGED_RESET=0 computes a reset when the episode ends instead of preparing it ahead.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1115,8 +1115,10 @@ struct LunarLanderEnv final : Env {
         dev.prep = 0; dev.episode_src = nullptr;
         // (pays while the step is bound by the contact kernel's chain: 131 072 envs 1.43 -> 1.36 ms per step, 262 144 1.50 -> 1.46,
         // 393 216 1.67 -> 1.60; a population that fills every wave slot gains nothing from moving the reset work and loses to the
-        // extra launches: 524 288 envs 1.86 -> 1.83, 1 Mi envs 3.53 -> 3.84; MGYM_LL_STAGED_RESET=2 forces it on)
-        staged = (staged == 2 || (staged == 1 && n < 524288)) && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
+        // extra launches: 524 288 envs 1.86 -> 1.83, 1 Mi envs 3.53 -> 3.84 — with one column per word.  With records the copy of a prepared
+        // state moves nine whole lines and staging pays at every size: 524 288 envs 1.55 -> 1.46, 786 432 2.27 -> 2.18, 1 Mi 2.57 -> 2.52,
+        // 2 Mi 5.67 -> 5.56 — profiles/r03_lunarlander/population_block_matrix.txt)
+        staged = staged >= 1 && (cfg.flags & MGYM_FLAG_AUTO_RESET) && !general_only;
         if (staged) {
             MGYM_HIP(hipMalloc(&shadow_base, (size_t)ll_state_words(n_pad) * sizeof(uint32_t)));
             MGYM_HIP(hipMemsetAsync(shadow_base, 0, (size_t)ll_state_words(n_pad) * sizeof(uint32_t), stream));
