@@ -763,6 +763,9 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
             unsigned long long hand[kFreePerLane], any = 0ull;
 #pragma unroll
             for (int q = 0; q < kFreePerLane; ++q) { hand[q] = __ballot(tg[q]); any |= hand[q]; }
+#ifdef LL_DIAG_DROP_HANDOVERS   // diagnostic builds (tools/ll_role_time.sh): what does the free-flight role cost WITHOUT taking its hand-overs through the contact path? (breaks the physics)
+            any = 0ull;
+#endif
             if (any != 0ull) {   // (about one wave in three)
                 const unsigned long long below = (1ull << threadIdx.x) - 1ull;
                 int at = 0;
