@@ -296,15 +296,19 @@ LLD int clip_segment(ClipV vOut[2], const ClipV vIn[2], V2 normal, float offset,
 // b2CollideEdgeAndPolygon (v2.4.1 form), two-sided edge in the ground frame (xfA = identity => xf = xfB)
 // `tmp`: room for 2 * kMaxPoly vectors (the polygon's vertices and normals in the edge's frame, indexed at run time) supplied by
 // the caller — World::poly_tmp, which is LDS when the World record is (a local array here would be scratch memory)
-LL_NOINLINE void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab, int pi, Xf xfB, V2* tmp) {
+// On the device both `tab_in` (every kernel stages the polygon table in LDS) and `tmp` (WorldTmp::poly_tmp, or a helper lane's piece of the
+// constraint columns) ARE LDS: an out-of-line function only sees generic pointers, and a generic access to LDS is a FLAT instruction —
+// the address-space casts below turn the ~50 of them in here into ds_read / ds_write.
+LL_NOINLINE void collide_edge_polygon(Manifold& manifold, V2 v1, V2 v2, const PolyTab& tab_in, int pi, Xf xfB, V2* tmp) {
+    const LL_LDS PolyTab& tab = *(const LL_LDS PolyTab*)&tab_in;
     manifold.pointCount = 0;
     const Xf xf = xfB;
     V2 edge1 = v2 - v1;
     normalize(edge1);
     V2 normal1 = mk(edge1.y, -edge1.x);
     const int tcount = tab.count[pi];
-    V2* const tv = tmp;
-    V2* const tn = tmp + kMaxPoly;
+    LL_LDS V2* const tv = (LL_LDS V2*)tmp;
+    LL_LDS V2* const tn = tv + kMaxPoly;
     for (int i = 0; i < tcount; ++i) {
         tv[i] = xmul(xf, tab.v[pi][i]);
         tn[i] = rmul(xf.q, tab.n[pi][i]);
