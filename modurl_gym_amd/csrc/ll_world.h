@@ -1297,6 +1297,9 @@ LLD int toi_advance(World& w, const PolyTab& tab, const LLConst& k, const CSolve
         }
         body_set_awake(bB, true);
         LL_STAMP(17);
+#ifdef LL_DIAG_SUBSTEP_LANES
+        LL_DIAG_SUBSTEP_LANES();   // tools/ll_phase_prof.hip: how many lanes of the wave take this sub-step
+#endif
 
         uint8_t* const islandSlots = (uint8_t*)w.t->idx[2];
         int nc = 0;

@@ -10,6 +10,8 @@ __device__ unsigned long long g_blkcnt[8192 * 24];
 #define LL_STAMP(id) do { if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)__ballot(1)) - 1) { unsigned long long t_ = __builtin_readcyclecounter(); \
     if (id != 0) { atomicAdd(&g_prof[id], t_ - s_last); atomicAdd(&g_cnt[id], 1ull); if (blockIdx.x < 8192) { g_blk[blockIdx.x * 24 + id] += t_ - s_last; g_blkcnt[blockIdx.x * 24 + id] += 1; } } s_last = t_; } } while (0)
 static __device__ __shared__ unsigned long long s_last;
+// lanes of the wave that take a sub-step, summed over the wave's passes of one launch (slot 19 of the per-block COUNT table)
+#define LL_DIAG_SUBSTEP_LANES() do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll(m_) - 1 && blockIdx.x < 8192) g_blkcnt[blockIdx.x * 24 + 19] += (unsigned long long)__popcll(m_); } while (0)
 // sweep-state cycle diagnostics: per lane, hash the state after every sweep; record the first sweep at which the
 // hash equals the one 1..4 sweeps earlier (period p), or 180 if never.  g_cyc[kind][period 0..4][bucket of 10 sweeps]
 __device__ unsigned long long g_cyc[2][5][19];
@@ -52,6 +54,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), z, sizeof z));
     static unsigned long long hb[8192 * 24], hc[8192 * 24], zz[8192 * 24];
     std::vector<double> all_tot;
+    static double tab_t[6][7], tab_n[6][7];
     double worst_phase[24] = {0}, worst_cnt[24] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
     for (int t = 0; t < steps; ++t) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), zz, sizeof zz)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blkcnt), zz, sizeof zz));
@@ -60,6 +63,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_blk), sizeof hb)); CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_blkcnt), sizeof hc));
         int wb = -1; double wt = 0;
         for (int b = 0; b < 8192; ++b) { double tt = 0; for (int q = 0; q < 24; ++q) tt += (double)hb[b * 24 + q]; if (tt > 0) { mean_tot += tt; nwaves++; all_tot.push_back(tt); } if (tt > wt) { wt = tt; wb = b; } }
+        for (int b = 0; b < 8192; ++b) {   // contact-role blocks (they pass Collide): time by sub-step passes and by lanes x sub-steps
+            if (!hc[b * 24 + 1]) continue;
+            double tt = 0; for (int q = 0; q < 24; ++q) tt += (double)hb[b * 24 + q];
+            const int passes = (int)std::min<unsigned long long>(hc[b * 24 + 17], 5), ls = (int)hc[b * 24 + 19];
+            const int col = ls == 0 ? 0 : ls <= 2 ? 1 : ls <= 4 ? 2 : ls <= 6 ? 3 : ls <= 9 ? 4 : ls <= 13 ? 5 : 6;
+            tab_t[passes][col] += tt; tab_n[passes][col] += 1;
+        }
         if (wb >= 0) { worst_tot += wt; for (int q = 0; q < 24; ++q) { worst_phase[q] += (double)hb[wb * 24 + q]; worst_cnt[q] += (double)hc[wb * 24 + q]; } }
     }
     CK(hipStreamSynchronize(env.stream));
@@ -76,6 +86,8 @@ int main(int argc, char** argv) {
     { unsigned long long cyc[2][5][19]; CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof cyc));
       for (int k = 0; k < 2; ++k) for (int p = 0; p < 5; ++p) { unsigned long long t = 0; for (int b = 0; b < 19; ++b) t += cyc[k][p][b]; if (!t) continue;
         printf("%s sweeps, <=2 contacts: period %d (0 = none found) n=%llu; first-detected-at histogram by 10 sweeps:", k ? "toi" : "island", p, t); for (int b = 0; b < 19; ++b) printf(" %llu", cyc[k][p][b]); printf("\n"); } }
+    printf("contact-role blocks: mean cycles (count) by passes with a sub-step (rows 0..5+) and by lane-sub-steps of the block (columns 0, 1-2, 3-4, 5-6, 7-9, 10-13, 14+):\n");
+    for (int a = 0; a < 6; ++a) { printf("  %d:", a); for (int b = 0; b < 7; ++b) if (tab_n[a][b] > 0) printf("  %8.0f (%6.0f)", tab_t[a][b] / tab_n[a][b], tab_n[a][b]); else printf("  %8s (%6d)", "-", 0); printf("\n"); }
     std::sort(all_tot.begin(), all_tot.end());
     if (!all_tot.empty()) {
         printf("per-block cycles (all launches): ");
