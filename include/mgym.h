@@ -10,7 +10,8 @@
  *
  * Conventions
  *  - All `*_out` / `actions` / `mask` / `blob` pointers are DEVICE pointers on the
- *    env's HIP device.  The engine owns only its internal SoA state; callers own
+ *    env's HIP device.  The engine owns only its internal state (its layout is private: columns for
+ *    CartPole / MountainCar, one record per env for LunarLander — DESIGN.md section 3); callers own
  *    every buffer they pass.  No allocation or synchronisation happens inside
  *    mgym_reset/mgym_step/mgym_reset_done (they are hipGraph-capturable).
  *  - Observations are SoA: obs_out[k * n_envs + i] is component k of env i
