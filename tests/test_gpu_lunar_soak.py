@@ -74,3 +74,11 @@ def test_soak_with_every_velocity_constraint_in_the_global_workspace(monkeypatch
     monkeypatch.setenv("MGYM_LL_VC_NEAR", "0")
     episodes, landed, _ = soak(8192, 500, seed=7)
     assert episodes > 10000
+
+
+@pytest.mark.parametrize("n", [1, 33, 97, 1000])
+def test_ragged_populations_every_word_equals_the_oracle(n):
+    # populations that fill neither a 32-lane contact block, a 64-lane free-flight wave nor the 1 024-env padding of the
+    # engine's allocation (one 288-word record per env): 400 steps with the fused auto-reset, every word against the oracle
+    episodes, _, _ = soak(n, 400, seed=1234 + n)
+    assert episodes >= (1 if n == 1 else n)
