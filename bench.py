@@ -159,7 +159,8 @@ class Stepper:
 
     def build_timed_graph(self, steps):
         """ONE graph of exactly `steps` step launches: a short timed region is then a single hipGraphLaunch (no eager
-        tail, no second replay)."""
+        tail, no second replay).  (Event records captured INTO the graph cannot be timed on this HIP: hipEventElapsedTime
+        returns hipErrorInvalidHandle for them; the records stay on the stream, around the launch.)"""
         self.timed = (steps, self.env.graph_capture(lambda: [self.one(k) for k in range(steps)]))
 
     def run_timed(self, steps):
@@ -352,6 +353,7 @@ def main():
 
     # short timed regions (the driver runs --steps 20): ONE graph of exactly K launches with the event records inside
     one_graph = args.steps <= 256
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for s in steppers:
         if s.launch == "graph":
             s.build_graph(args.warmup)   # capture + instantiate before anything is timed, whatever the warm-up length
@@ -365,16 +367,20 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    lead.env.timer_start()            # hipEvent on the launch stream
+    # HIP events on the LAUNCH stream of the lead family (torch events recorded on that stream, not on torch's current one); the second
+    # one is only recorded inside the wall-clock window — waiting for it and reading it happen after t1, so the window holds the K
+    # launches, one event record and the device synchronisation, nothing else
+    ev_a.record(streams[0])
     t0 = time.perf_counter()
     for s in steppers:
         if s.launch == "graph" and one_graph:
             s.run_timed(args.steps)   # EXACTLY K steps: one hipGraphLaunch
         else:
             s.run(args.steps)         # EXACTLY K steps (graph replays, or eager launches)
-    ev_ms = lead.env.timer_stop()     # second hipEvent + hipEventSynchronize
+    ev_b.record(streams[0])
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    ev_ms = ev_a.elapsed_time(ev_b)
     barrier()
     elapsed = t1 - t0
     if dist is not None:
