@@ -857,7 +857,7 @@ LL_NOINLINE void island_sweeps(Joint& J0_io, Joint& J1_io, Vel3& vel_io, CSolver
 // becomes so within a few dozen sweeps: one body against static ground settles on a fixed point (period 1) or on a
 // short cycle of last-bit flips.  Once S_j == S_i bit for bit (i < j, p = j - i), S_180 = S_{j + (180 - j) mod p}:
 // only (180 - j) mod p more sweeps are run, with the identical result.  S_j is compared with the previous state
-// (fixed point, found at once) and with a snapshot renewed at j = 1, 2, 4, 8, ... (Brent's cycle search: any period
+// (fixed point) and with a snapshot renewed at doubling distances (Brent's cycle search: any period
 // is found once the snapshot lies on the cycle and the window exceeds the period).  The joints of the full island
 // never settle this way, which is why island_sweeps has no such exit.
 // What is left (tools/ll_work_stats.sh: 4 % of one-constraint and 21 % of two-constraint sub-steps run all 180
@@ -955,16 +955,34 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
         for (int q = 1; q < 11; ++q) f = (f << 3) + (f >> 29) + st.w[q] * (uint32_t)(2 * q + 1);
         return f;
     };
+    // The exits are looked for after every 16th sweep only.  Looking costs ~100 instructions (two state captures, two digests, the
+    // comparisons) beside a ~350-instruction sweep, and a wave leaves the loop when its LAST lane does: measured at 262 144 envs, looking after
+    // every sweep 1.082 ms per step, every 4th (after 32 dense ones) 1.048, every 8th 1.008, every 16th 0.995, every 32nd 1.015, every 64th
+    // 1.09, never 1.23 (profiles/r03_lunarlander/ab_records.txt).  An exit seen late changes nothing: a fixed point stays one, a cycle is
+    // met again at a later multiple of its period, a settled velocity stays settled.  (LL_TOI_CHECK_DENSE: look after every sweep up to
+    // there; LL_TOI_CHECK_EVERY, a power of two, and LL_TOI_CHECK_PHASE: afterwards when (sweeps done) mod EVERY == PHASE.)
+#ifndef LL_TOI_CHECK_DENSE
+#define LL_TOI_CHECK_DENSE 0
+#endif
+#ifndef LL_TOI_CHECK_EVERY
+#define LL_TOI_CHECK_EVERY 16
+#endif
+#ifndef LL_TOI_CHECK_PHASE
+#define LL_TOI_CHECK_PHASE (LL_TOI_CHECK_EVERY - 1)
+#endif
+    constexpr int kEverySweep = LL_TOI_CHECK_DENSE, kLookMask = LL_TOI_CHECK_EVERY - 1, kLookPhase = LL_TOI_CHECK_PHASE;
     ToiSweepState prev = state_now(), snap = prev;
     uint32_t prev_f = digest(prev), snap_f = prev_f;
     int done = 0, left = LL_WI_LIMIT(180), snap_at = 0, next_snap = 1;
     LL_DIAG_SWEEP_BEGIN(1);
     while (left > 0) {
+        const bool look = can_stop && (done < kEverySweep || (done & kLookMask) == kLookPhase);   // ... after the sweep that is about to run
+        if (look && done >= kEverySweep) { prev = state_now(); prev_f = digest(prev); }   // the state before the sweep (below kEverySweep `prev` is the last sweep's `cur`)
         if (h0) cs_solve_one(r0, vd);
         if (h1) cs_solve_one(r1, vd);
         if (cs.count > 2) cs_solve_velocity_range(cs, 2, cs.count, vd);
         ++done; --left;
-        if (can_stop) {
+        if (look) {
             const ToiSweepState cur = state_now();
             LL_DIAG_SWEEP(1, done - 1, true, vd.v.x, vd.v.y, vd.w, h0 ? r0.points[0].normalImpulse : 0.0f, h0 ? r0.points[0].tangentImpulse : 0.0f,
                           h0 && r0.pointCount > 1 ? r0.points[1].normalImpulse : 0.0f, h0 && r0.pointCount > 1 ? r0.points[1].tangentImpulse : 0.0f,
@@ -976,7 +994,7 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
             const uint32_t cur_f = digest(cur);
             if (cur_f == prev_f && toi_state_same(cur, prev)) break;                                                // fixed point
             if (cur_f == snap_f && toi_state_same(cur, snap)) { left %= done - snap_at; can_stop = false; }          // on a cycle of period done - snap_at
-            else if (done == next_snap) { snap = cur; snap_f = cur_f; snap_at = done; next_snap *= 2; }
+            else if (done >= next_snap) { snap = cur; snap_f = cur_f; snap_at = done; next_snap = 2 * done; }
             if (can_settle && can_stop && done >= settle_at && cur.w[0] == prev.w[0] && cur.w[1] == prev.w[1] && cur.w[2] == prev.w[2]) {
                 if ((!h0 || toi_velocity_settled_one(r0, vd)) && (!h1 || toi_velocity_settled_one(r1, vd))) break;   // the velocity is final
                 settle_at = 2 * done;
@@ -1020,7 +1038,9 @@ LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1,
     if (h1) q1 = cs.pc[n_ps];
     bool solved = false;
     for (int it = 0; it < LL_WI_LIMIT(60); ++it) {
-        const Pos3 before = pos;
+        const bool look = (it & 7) == 7;   // the fixed-point exit is looked for after every 8th iteration (it has not fired once in the host statistics' 134 038 solves)
+        Pos3 before;
+        if (look) before = pos;
         float minSeparation = 0.0f;
         if (h0) pc_solve_on(q0, pos, minSeparation);
         if (h1) pc_solve_on(q1, pos, minSeparation);
@@ -1038,7 +1058,7 @@ LL_NOINLINE bool island_position(Pos3& pos_io, const Joint& J0, const Joint& J1,
         LL_POS_ITER_TRACE(it, pos);
 #endif
         if (contactsOkay && okA && okB) { solved = true; LL_POS_ITER_STAT(0, n_cs, it + 1, 1); break; }
-        if (pos_same(before.b0, pos.b0) && pos_same(before.b1, pos.b1) && pos_same(before.b2, pos.b2)) { LL_POS_ITER_STAT(0, n_cs, it + 1, 2); break; }
+        if (look && pos_same(before.b0, pos.b0) && pos_same(before.b1, pos.b1) && pos_same(before.b2, pos.b2)) { LL_POS_ITER_STAT(0, n_cs, it + 1, 2); break; }
         if (it == 59) LL_POS_ITER_STAT(0, n_cs, 60, 0);
     }
     pos_io = pos;
