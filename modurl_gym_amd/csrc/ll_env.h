@@ -79,6 +79,7 @@ struct LLDev {
     int fused_tail;  // fused order of step(): lists and counters are maintained by ll_epilogue_kernel (lunar_lander.hip)
     int resume;  // the free-flight kernel stores the post-solve state of an env it has to hand over (F_RESUME); the contact kernel continues from it
     int split;   // 0: sequential launch order; 1: overlapped (contact list built by ll_classify_kernel; the free-flight kernel lists only what it declines)
+    int contact_blocks;  // single-launch step: how many contact blocks the list is dealt out over (each takes list / contact_blocks lanes, 8..32); 0: 32 lanes per block
 #ifdef LL_WHATIF_BUILD
     uint32_t whatif;  // tools/ll_whatif.hip only
 #endif

@@ -375,7 +375,8 @@ LLD uint64_t ll_list_entry(const ContactList& L, uint64_t q, uint64_t total) {
 // (S.tab must have been staged.)
 template <int BLK>
 __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, int toi_budget, const ContactList& CL, uint64_t q_first, uint64_t q_stride,
-                                                VConstraint* far_lane0, int far_stride, ContactLds<BLK>& S, bool& not_reset, uint32_t& overflow, uint32_t& finished) {
+                                                VConstraint* far_lane0, int far_stride, ContactLds<BLK>& S, bool& not_reset, uint32_t& overflow, uint32_t& finished,
+                                                int fill = BLK /* lanes of the block that take a list entry (the single-launch step deals a short list out over more blocks) */) {
     constexpr bool kWorldLds = BLK <= 32;
     constexpr int kThreads = ll_contact_threads(BLK);
     const PolyTab& tab = S.tab;
@@ -389,7 +390,7 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
     const uint64_t total = CL.c0_up + CL.c1;
     for (uint64_t q0 = q_first; q0 < total; q0 += q_stride) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
-        const bool have = env_lane && (q < CL.c0 || (q >= CL.c0_up && q < total));
+        const bool have = env_lane && (int)threadIdx.x < fill && (q < CL.c0 || (q >= CL.c0_up && q < total));
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
         bool stepping = false;      // this lane is inside world.step
@@ -749,10 +750,21 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
         CL.list = d.work_list + (uint64_t)L_GENERAL * d.n_pad; CL.back = 0; CL.c0 = d.work_count[L_GENERAL]; CL.c1 = 0; CL.spread = false;
         CL.c0_up = (CL.c0 + BLK - 1) / BLK * BLK;
         if (blockIdx.x == 0 && threadIdx.x == 0) { d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u; }   // (consumed by the last launches of the previous call)
-        if ((uint64_t)blockIdx.x * BLK >= CL.c0) return;   // most blocks of this role: the list is far shorter than the grid
+        // LANES PER BLOCK by the length of the list: the step ends with the slowest contact block, and a block's chain grows with the lanes
+        // it carries (sub-step passes = the maximum over its lanes, every pass as long as its slowest lane) — so a short list is dealt out
+        // over MORE blocks of fewer lanes, as many as run at once beside the free-flight role (d.contact_blocks, from the population).
+        // 65 536 envs: 0.95 -> 0.79 ms per step, 131 072: 0.99 -> 0.85, 196 608: 1.00 -> 0.92, 262 144: 1.00 -> 0.98
+        // (profiles/r03_lunarlander/block_lanes_by_population.txt).  The lanes per block follow THIS step's list, so a policy that keeps more
+        // envs on the ground simply gets fuller blocks.
+        uint32_t fill = BLK;
+        if (d.contact_blocks > 0) {
+            fill = (uint32_t)((CL.c0 + (uint64_t)d.contact_blocks - 1) / (uint64_t)d.contact_blocks);
+            fill = fill < 8u ? 8u : fill > (uint32_t)BLK ? (uint32_t)BLK : fill;
+        }
+        if ((uint64_t)blockIdx.x * fill >= CL.c0) return;   // most blocks of this role: the list is far shorter than the grid
         stage_tab(S.tab, LLK(d));
-        ll_contact_body<BLK>(d, io, -1, CL, (uint64_t)blockIdx.x * BLK, (uint64_t)g_contact * BLK, d.vc_far + (uint64_t)blockIdx.x * BLK, (int)(g_contact * BLK),
-                             S, not_reset, overflow, finished);
+        ll_contact_body<BLK>(d, io, -1, CL, (uint64_t)blockIdx.x * fill, (uint64_t)g_contact * fill, d.vc_far + (uint64_t)blockIdx.x * BLK, (int)(g_contact * BLK),
+                             S, not_reset, overflow, finished, (int)fill);
     } else if (blockIdx.x < g_contact + g_free) {
         const unsigned fb = blockIdx.x - g_contact;
         stage_tab(S.tab, LLK(d));
@@ -1029,6 +1041,7 @@ struct LunarLanderEnv final : Env {
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int fused_tail = getenv("MGYM_LL_FUSED_TAIL") ? atoi(getenv("MGYM_LL_FUSED_TAIL")) : 1;  // 1 (default): the fused order of step() (ll_epilogue_kernel); needs the overlapped order and none of the profiling knobs
     int single_launch = getenv("MGYM_LL_SINGLE_LAUNCH") ? atoi(getenv("MGYM_LL_SINGLE_LAUNCH")) : 1;  // 1 (default): contact path, free-flight path and reset preparation in ONE launch (ll_step_kernel); needs the fused order and 32-lane contact blocks
+    int contact_blocks = getenv("MGYM_LL_CONTACT_BLOCKS") ? atoi(getenv("MGYM_LL_CONTACT_BLOCKS")) : -1;  // single-launch step: blocks the contact list is dealt out over (-1: by population, 0: always 32 lanes per block)
     int resume = getenv("MGYM_LL_RESUME") ? atoi(getenv("MGYM_LL_RESUME")) : 1;  // 1 (default): envs the free-flight kernel stops at a new contact are resumed after their island solve (0: redone from the old state)
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
@@ -1082,6 +1095,10 @@ struct LunarLanderEnv final : Env {
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
         dev.bucket = bucket;
         dev.resume = resume && !general_only;
+        // contact blocks that run at once beside the free-flight role: 900 of the 1 024 one-wave-per-SIMD slots (measured 750 .. 1 000 at
+        // 65 536 .. 327 680 envs: flat within 1-2 % from 850 up, profiles/r03_lunarlander/block_lanes_by_population.txt)
+        if (contact_blocks < 0) contact_blocks = 900;
+        dev.contact_blocks = contact_blocks;
         fused_tail = fused_tail && overlap && !general_only && toi_rounds == 0 && bucket == 0;
         dev.fused_tail = fused_tail;
         single_launch = single_launch && fused_tail && gen_block == 32 && resume;
@@ -1416,7 +1433,7 @@ struct LunarLanderEnv final : Env {
     // mgym_get_info: the launch structure of this handle and whether its streams really run side by side
     int info(std::string& out) override {
         out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
-               "\nstaged_resets=" + (staged ? "1" : "0") + "\n";
+               "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) + "\n";
         hipStream_t ss[3] = {stream, aux, aux2};
         const int ns = aux2 ? 3 : 2;
         unsigned long long* d_t = nullptr;

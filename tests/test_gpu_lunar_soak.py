@@ -82,3 +82,12 @@ def test_ragged_populations_every_word_equals_the_oracle(n):
     # engine's allocation (one 288-word record per env): 400 steps with the fused auto-reset, every word against the oracle
     episodes, _, _ = soak(n, 400, seed=1234 + n)
     assert episodes >= (1 if n == 1 else n)
+
+
+@pytest.mark.parametrize("blocks", [0, 12, 40])
+def test_soak_with_other_lanes_per_contact_block(blocks, monkeypatch):
+    # the single-launch step deals its contact list out over MGYM_LL_CONTACT_BLOCKS blocks (default 900: 8 lanes per block at this
+    # population); 0 = always 32 lanes per block, 12 / 40 = ~30 / ~9 lanes — the grouping must not change a word
+    monkeypatch.setenv("MGYM_LL_CONTACT_BLOCKS", str(blocks))
+    episodes, _, _ = soak(4096, 500, seed=4321)
+    assert episodes > 6000
