@@ -171,7 +171,7 @@ __device__ __forceinline__ void ll_load(const LLDev& d, uint64_t i, World& w, En
     e.deterministic = flags & F_DETERMINISTIC;
 }
 
-__device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e, bool mid = false) {
+__device__ __forceinline__ uint32_t ll_store(const LLDev& d, uint64_t i, const World& w, const EnvRegs& e, bool mid = false) {   // -> the flag word it stored
     uint32_t flags = 0, ncont = 0, touching = 0;
     for (int b = 0; b < 3; ++b) {
         const Body& bd = w.b[b];
@@ -217,6 +217,7 @@ __device__ __forceinline__ void ll_store(const LLDev& d, uint64_t i, const World
     ST(C_PREV) = as_u32(e.prev_shaping);
     ST(C_WIND) = (uint32_t)e.wind_idx; ST(C_TORQUE) = (uint32_t)e.torque_idx;
     ST(C_STEP) = e.step; ST(C_EPISODE) = e.episode;
+    return flags;
 }
 
 // b2Body::ApplyForceToCenter / ApplyTorque / ApplyLinearImpulse on the lander (wake = true)

@@ -110,6 +110,14 @@ __device__ __forceinline__ bool ll_any_ground_overlap(const LLDev& d, uint64_t i
 //    above that overlaps nothing (aabb_overlap would say so for every edge: b.lo.y - a.hi.y > 0) and needs no terrain at all;
 //  * otherwise the 11 heights are fetched together (independent loads, one round trip) and tested from registers.
 constexpr float kTerrainTop = 6.75f;
+#if defined(__HIPCC__)
+#define LL_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define LL_LOAD_AGENT(p) (*(p))   // (the host build of this source, tests/native/ll_host_check.cpp)
+#endif
+// COH (ll_roll.h): the record may have been written by another compute unit during THIS launch — the terrain is fetched with
+// agent-scope loads (they bypass this compute unit's vector L1, which another unit's stores never refresh)
+template <bool COH = false>
 __device__ __forceinline__ bool ll_ground_overlap_any_of(const LLDev& d, uint64_t i, const AABB fat[3], uint32_t mask) {
     uint32_t need = 0u;
 #pragma unroll
@@ -118,7 +126,7 @@ __device__ __forceinline__ bool ll_ground_overlap_any_of(const LLDev& d, uint64_
     if (need == 0u) return false;
     float sm[kEdges];
 #pragma unroll
-    for (int q = 0; q < kEdges; ++q) sm[q] = as_f32(ST(C_SMOOTH + q));
+    for (int q = 0; q < kEdges; ++q) sm[q] = as_f32(COH ? LL_LOAD_AGENT(&ST(C_SMOOTH + q)) : ST(C_SMOOTH + q));
     bool any = false;
 #pragma unroll
     for (int e = 0; e < kEdges; ++e) {
@@ -201,10 +209,11 @@ struct FreeSolve { Pos pos[3]; Vel vel[3]; float m_power, s_power; };
 constexpr float kFreeDt = 1.0f / 50.0f;
 
 // wind / engines and b2Island::Solve up to the velocity sweeps; false: FREE_DECLINED (nothing was changed that matters: f, e are the caller's copies)
+template <bool COH = false>
 __device__ __forceinline__ bool ll_free_begin(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, uint32_t action, float disp0, float disp1, FreeSolve& s) {
     const LLConst& k = LLK(d);
     if (f.flags & F_NEW_CONTACTS) {  // b2World::Step: pending FindNewContacts (after reset / set_state)
-        if (ll_ground_overlap_any_of(d, i, f.fat, (f.flags >> 9) & 7u)) return false;
+        if (ll_ground_overlap_any_of<COH>(d, i, f.fat, (f.flags >> 9) & 7u)) return false;
     }
     ll_pre_step(f.b[0], f.flags & F_LEG0, f.flags & F_LEG1, e, k, action, disp0, disp1, s.m_power, s.s_power);
 
@@ -229,6 +238,7 @@ __device__ __forceinline__ void ll_free_sweep(FreeRegs& f, const LLConst& k, Fre
     rj_solve_velocity(f.jt[0], 0, k, s.vel[0].v, s.vel[0].w, s.vel[1].v, s.vel[1].w, dt, inv_dt);
 }
 // positions, sleep, broad phase, observation / reward / termination
+template <bool COH = false>
 __device__ __forceinline__ int ll_free_finish(const LLDev& d, uint64_t i, FreeRegs& f, EnvRegs& e, const PolyTab& tab, FreeSolve& s,
                                               float state[8], float& reward, uint32_t& done, uint32_t& moved) {
     const LLConst& k = LLK(d);
@@ -272,7 +282,7 @@ __device__ __forceinline__ int ll_free_finish(const LLDev& d, uint64_t i, FreeRe
         V2 c1 = 0.5f * (a1.lo + a1.hi), c2 = 0.5f * (a2.lo + a2.hi);
         if (ll_free_move_proxy(f.fat[b], aabb, c2 - c1)) moved |= 1u << b;
     }
-    create = ll_ground_overlap_any_of(d, i, f.fat, moved);  // a contact would be created: the contact path takes over from here
+    create = ll_ground_overlap_any_of<COH>(d, i, f.fat, moved);  // a contact would be created: the contact path takes over from here
     if (create) return FREE_RESUME;
     // SolveTOI: no contacts.  ClearForces; inv_dt0 = inv_dt.
     ll_post_step(f.b[0], f.flags & F_GAME_OVER, f.flags & F_LEG0, f.flags & F_LEG1, e, s.m_power, s.s_power, state, reward, done);

@@ -813,6 +813,10 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
     ll_report(d, not_reset, overflow, finished);
 }
 
+}  // namespace mgym
+#include "ll_roll.h"   // mgym_rollout: K steps in one persistent launch, environments advancing independently
+namespace mgym {
+
 // Staged resets.  The state an env has after reset() — scene, implicit step(0), observation — is a pure function of
 // (seed, env id, episode counter), so it does not have to be computed when the episode ends, on the critical path of
 // that step (reset kernel: 0.11 ms behind the contact kernel): it is PREPARED in advance, in shadow columns, by the same
@@ -1045,6 +1049,13 @@ struct LunarLanderEnv final : Env {
     int resume = getenv("MGYM_LL_RESUME") ? atoi(getenv("MGYM_LL_RESUME")) : 1;  // 1 (default): envs the free-flight kernel stops at a new contact are resumed after their island solve (0: redone from the old state)
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
+    // mgym_rollout as ONE persistent launch (ll_roll.h); MGYM_LL_ROLLOUT=0: K x step()
+    int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : 0;   // (off by default until it is faster than K x step())
+    void* roll_ring = nullptr;
+    void* roll_ctl = nullptr;
+    void* roll_vc_far = nullptr;
+    RollQ rq{};
+    unsigned roll_grid = 0;
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
@@ -1052,6 +1063,9 @@ struct LunarLanderEnv final : Env {
         if (work_base) (void)hipFree(work_base);
         if (kdev) (void)hipFree(kdev);
         if (vc_far_base) (void)hipFree(vc_far_base);
+        if (roll_ring) (void)hipFree(roll_ring);
+        if (roll_ctl) (void)hipFree(roll_ctl);
+        if (roll_vc_far) (void)hipFree(roll_vc_far);
         if (aux) (void)hipStreamDestroy(aux);
         if (env_class) (void)hipFree(env_class);
         if (aux2) { (void)hipStreamSynchronize(aux2); (void)hipStreamDestroy(aux2); }
@@ -1151,6 +1165,56 @@ struct LunarLanderEnv final : Env {
             MGYM_HIP(hipEventCreateWithFlags(&ev_prepared, hipEventDisableTiming));
             MGYM_HIP(hipEventCreateWithFlags(&ev_free_done, hipEventDisableTiming));
         }
+        // mgym_rollout's persistent launch: rings of >= n slots per queue, one wave per SIMD as many as are resident at once, a slice of
+        // far-constraint workspace per wave.  (Records are addressed by 32-bit byte offsets there: n_pad x 1152 B < 4 GiB.)
+        roll_enabled = roll_enabled && !general_only && n > 0 && n <= kRollEnvMask && (uint64_t)n_pad * kRec * 4ull < 0xffffffffull;
+        if (roll_enabled) {
+            uint64_t cap = 64;
+            while (cap < n) cap <<= 1;
+            rq.mask = (uint32_t)(cap - 1);
+            MGYM_HIP(hipMalloc(&roll_ring, (size_t)cap * RQ_COUNT * sizeof(unsigned long long)));
+            MGYM_HIP(hipMalloc(&roll_ctl, (size_t)RC_WORDS * 32 * sizeof(uint32_t)));
+            rq.ring = static_cast<unsigned long long*>(roll_ring);
+            rq.ctl = static_cast<uint32_t*>(roll_ctl);
+            rq.contact_min = getenv("MGYM_LL_ROLL_CONTACT_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_CONTACT_MIN")) : 32u;
+            rq.refill_min = getenv("MGYM_LL_ROLL_REFILL_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_REFILL_MIN")) : 8u;
+            rq.debug = getenv("MGYM_LL_ROLL_DEBUG") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_DEBUG")) : 0u;
+            hipLaunchKernelGGL(ll_rollout_ring_init_kernel, dim3(256), dim3(256), 0, stream, rq);
+            int per_cu = 0, dev_id = 0;
+            hipDeviceProp_t prop;
+            MGYM_HIP(hipGetDevice(&dev_id));
+            MGYM_HIP(hipGetDeviceProperties(&prop, dev_id));
+            MGYM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ll_rollout_kernel<32>, 64, 0));
+            if (per_cu < 1) per_cu = 1;
+            uint64_t g = (uint64_t)per_cu * (uint64_t)prop.multiProcessorCount;
+            if (getenv("MGYM_LL_ROLL_GRID")) g = (uint64_t)atoi(getenv("MGYM_LL_ROLL_GRID"));
+            const uint64_t need = (n + 31) / 32;   // more waves than 32-lane batches can never be busy
+            if (g > need) g = need;
+            if (g < 1) g = 1;
+            roll_grid = (unsigned)g;
+            const size_t per_lane = (size_t)(kSolverCap - vc_near_limit);
+            MGYM_HIP(hipMalloc(&roll_vc_far, per_lane * (size_t)roll_grid * 32 * sizeof(VConstraint)));
+        }
+        return MGYM_OK;
+    }
+    // K steps of every environment in ONE persistent launch (ll_roll.h): identical per-environment results to K calls of step()
+    int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (!roll_enabled || n == 0 || K <= 0) return Env::rollout(actions, K, obs_out, reward, done, trunc);
+        int st = join_helpers();
+        if (st != MGYM_OK) return st;
+        LLDev rd = dev; rd.split = 0;
+        rd.vc_far = static_cast<VConstraint*>(roll_vc_far); rd.vc_far_late = rd.vc_far;
+        for (int k0 = 0; k0 < K; k0 += (int)kRollMaxK) {
+            const int kc = K - k0 < (int)kRollMaxK ? K - k0 : (int)kRollMaxK;
+            LLIo io{static_cast<const uint32_t*>(actions) + (size_t)k0 * n, obs_out ? obs_out + (size_t)k0 * 8 * n : nullptr, reward ? reward + (size_t)k0 * n : nullptr,
+                    done ? done + (size_t)k0 * n : nullptr, trunc ? trunc + (size_t)k0 * n : nullptr};
+            RollQ q = rq; q.K = (uint32_t)kc;
+            hipLaunchKernelGGL(ll_rollout_begin_kernel, dim3(1), dim3(64), 0, stream, q, (uint32_t)n);
+            hipLaunchKernelGGL(ll_rollout_kernel<32>, dim3(roll_grid), dim3(64), 0, stream, rd, io, q);
+        }
+        if (staged) direct_possible = true;   // episodes that ended inside the launch were reset there: their prepared successors no longer fit
+        if (fused_tail) { st = rebuild_list(); if (st != MGYM_OK) return st; }
+        MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
     bool staging() const { return staged && dev.disp == nullptr; }  // (a dispersion override would be baked into prepared states)
