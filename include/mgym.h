@@ -139,7 +139,11 @@ int mgym_step(mgym_env *env, const void *actions, float *obs_out, float *reward_
  * identical to K calls of mgym_step with the same per-step action columns, including the
  * MGYM_FLAG_AUTO_RESET behaviour between steps; for CartPole/MountainCar the state stays in registers
  * across the K steps, so per-step HBM traffic is the action read and the reward/flag writes only.
- * actions: [K][n_envs]; reward_out/done_out/trunc_out: [K][n_envs] or NULL; obs_out: [K][obs_dim][n_envs] or NULL. */
+ * actions: [K][n_envs]; reward_out/done_out/trunc_out: [K][n_envs] or NULL; obs_out: [K][obs_dim][n_envs] or NULL.
+ * LunarLander: ONE persistent launch in which every environment advances as soon as IT is ready (free-flight environments stay in
+ * registers from step to step, environments on the contact path travel through device queues in batches of their own kind, whatever step
+ * index each is at) — a step of mgym_step ends with its slowest environment, K steps of mgym_rollout cost the mean one.  Per-environment
+ * results are those of K mgym_step calls, word for word (the loop being fused: lunar_lander.rs:919-1167 called K times). */
 int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, float *reward_out,
                  uint8_t *done_out, uint8_t *trunc_out);
 
@@ -230,7 +234,15 @@ int mgym_timer_stop(mgym_env *env, float *elapsed_ms); /* synchronises */
  * sincos / cos of the LunarLander and MountainCar kernels}; all must be 0. */
 int mgym_selftest_cartpole_math(int device, uint64_t *mismatches);
 
-/* hipGraph capture of a caller-issued launch sequence on the env's stream. */
+/* hipGraph capture of a caller-issued launch sequence on the env's stream.  What a captured launch freezes and what it does not:
+ *  - environment STATE is read when the graph runs: mgym_set_state, mgym_reset (any form) and eager steps between replays are fine.
+ *    (LunarLander: a captured step always carries the launches that reset a finished environment WITHOUT a prepared next episode —
+ *    empty when every environment has one — because only the run can tell; reset semantics: lunar_lander.rs:727-917 incl. the implicit
+ *    step(0) at :911-916.)
+ *  - the handle's CONFIGURATION is frozen into kernel arguments: after mgym_set_dispersion_override (deterministic_mode,
+ *    lunar_lander.rs:967-970) mgym_graph_launch refuses graphs captured before it with MGYM_ERR_BAD_ARG — capture again.
+ *    The pointers passed to the captured calls are frozen too, of course.
+ * mgym_get_info may not be called between mgym_graph_begin and mgym_graph_end (it synchronises): MGYM_ERR_BAD_ARG. */
 int mgym_graph_begin(mgym_env *env);
 int mgym_graph_end(mgym_env *env, void **graph_exec_out);
 int mgym_graph_launch(mgym_env *env, void *graph_exec);

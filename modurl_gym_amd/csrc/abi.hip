@@ -398,6 +398,11 @@ int mgym_graph_begin(mgym_env* env) {
     return MGYM_OK;
 }
 
+// What mgym_graph_end hands out: the executable graph and the handle configuration it was captured under.  Kernel arguments are
+// frozen at capture — among them the dispersion source of mgym_set_dispersion_override — so a graph captured under another
+// configuration is refused at launch (loudly) instead of silently stepping with the old one.
+struct GraphBox { hipGraphExec_t exec; uint64_t config_epoch; };
+
 int mgym_graph_end(mgym_env* env, void** graph_exec_out) {
     ENV_OR_FAIL(env);
     if (!graph_exec_out) return bad_arg("mgym_graph_end: NULL");
@@ -408,18 +413,27 @@ int mgym_graph_end(mgym_env* env, void** graph_exec_out) {
     hipError_t err = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (err != hipSuccess) return hip_fail(err, "hipGraphInstantiate", __FILE__, __LINE__);
-    *graph_exec_out = ge;
+    *graph_exec_out = new GraphBox{ge, e->config_epoch};
     return MGYM_OK;
 }
 
 int mgym_graph_launch(mgym_env* env, void* graph_exec) {
     ENV_OR_FAIL(env);
-    MGYM_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), e->stream));
+    if (!graph_exec) return bad_arg("mgym_graph_launch: NULL");
+    GraphBox* b = static_cast<GraphBox*>(graph_exec);
+    if (b->config_epoch != e->config_epoch)
+        return bad_arg("mgym_graph_launch: the handle's configuration has changed since this graph was captured (mgym_set_dispersion_override): capture it again");
+    MGYM_HIP(hipGraphLaunch(b->exec, e->stream));
     return MGYM_OK;
 }
 
 int mgym_graph_destroy(void* graph_exec) {
-    if (graph_exec) MGYM_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    if (graph_exec) {
+        GraphBox* b = static_cast<GraphBox*>(graph_exec);
+        hipError_t err = hipGraphExecDestroy(b->exec);
+        delete b;
+        MGYM_HIP(err);
+    }
     return MGYM_OK;
 }
 

@@ -77,6 +77,7 @@ struct Env {
     virtual int join_helpers() { return MGYM_OK; }
     // mgym_get_info: family-specific "key=value" lines appended to `out` (may launch probe kernels and synchronise)
     virtual int info(std::string&) { return MGYM_OK; }
+    uint64_t config_epoch = 0;   // moves whenever something changes that captured launches have frozen into their arguments (abi.hip GraphBox)
     std::string hwq_env;   // GPU_MAX_HW_QUEUES as the environment held it at mgym_create ("unset" if absent)
     virtual int set_dispersion(const float*) { set_last_error("dispersion override: LunarLander only"); return MGYM_ERR_BAD_ARG; }
 };

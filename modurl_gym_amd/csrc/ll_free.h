@@ -205,6 +205,9 @@ __device__ __forceinline__ void ll_free_store_resume(const LLDev& d, uint64_t i,
 // In three pieces — begin, 180 x sweep, finish — so that a lane can take TWO environments through the sweeps side by side
 // (lunar_lander.hip ll_free_pass2: two independent dependent chains in one instruction stream).
 enum { FREE_DECLINED = 0, FREE_DONE = 1, FREE_RESUME = 2 };
+#ifndef LL_FREE_POS_STAT
+#define LL_FREE_POS_STAT(iters)   // host statistics builds count the joint position iterations of a free-flight step (61: ran out of its 60)
+#endif
 struct FreeSolve { Pos pos[3]; Vel vel[3]; float m_power, s_power; };
 constexpr float kFreeDt = 1.0f / 50.0f;
 
@@ -251,7 +254,8 @@ __device__ __forceinline__ int ll_free_finish(const LLDev& d, uint64_t i, FreeRe
     for (int it = 0; it < 60; ++it) {
         bool ok1 = rj_solve_position(f.jt[1], 1, k, pos[0], pos[2]);
         bool ok0 = rj_solve_position(f.jt[0], 0, k, pos[0], pos[1]);
-        if (ok1 && ok0) { positionSolved = true; break; }
+        if (ok1 && ok0) { positionSolved = true; LL_FREE_POS_STAT(it + 1); break; }
+        if (it == 59) LL_FREE_POS_STAT(61);
     }
 #pragma unroll
     for (int b = 0; b < 3; ++b) {

@@ -32,18 +32,47 @@ namespace mgym {
 
 typedef uint32_t ll_u32x4 __attribute__((ext_vector_type(4)));
 
-enum { RQ_FREE = 0, RQ_CONTACT = 1, RQ_RESET = 2, RQ_COUNT = 3 };
-// control words, each on a 128-byte line of its own
-enum { RC_HEAD = 0 /* + queue */, RC_TAIL = 3 /* + queue */, RC_CHUNK = 6, RC_LIVE = 7, RC_ABORT = 8, RC_STAT = 9 /* .. 15: diagnostics */, RC_WORDS = 16 };
+// RQ_CONTACT: environments that ended their last step with a TOUCHING contact (island solves with contact constraints, position solves that run out of
+// their 60 iterations half of the time, 59 % take time-of-impact sub-steps); RQ_LIGHT: the other three quarters of the contact path's population
+// (cached contacts that do not touch yet, hand-overs: joints-only islands that converge in 2-4 position iterations, 13 % take a sub-step).  A wave is
+// as slow as its slowest lane, so the two kinds travel in separate batches — which lengthens the longest chain of a lock-step step (measured in
+// round 2: not kept there) and is exactly right when nothing waits for the longest chain.
+enum { RQ_FREE = 0, RQ_CONTACT = 1, RQ_RESET = 2, RQ_LIGHT = 3, RQ_COUNT = 4 };
+// control words, each on a 128-byte line of its own.  Per queue: TAIL (ring positions handed to producers, fetch-add), HEAD (ring positions
+// handed to consumers, fetch-add) and AVAIL, a counting semaphore of published entries: a consumer subtracts what it wants and gives back
+// what it did not get, so taking entries costs every wave a fixed number of atomics however many waves want the same entries (a
+// compare-and-swap on HEAD made 1 024 waves retry each other: 830 failed rounds per wave and launch, measured).
+// HEADT: the step index of the entry taken most recently from a queue (a hint: rings hand entries out lowest step index first, roughly).  Waves serve
+// the queue that is furthest BEHIND, so that all kinds of environments advance at one pace: with fixed priorities the contact path's population ran
+// ahead, free-flight environments started late, and the ones among them that reached the ground in their last steps were taken through their
+// remaining steps one 0.4-0.7 ms batch at a time while 900 waves idled (timeline: profiles/r04_lunarlander/rollout_timeline_*.txt).
+enum { RC_AVAIL = 0 /* + queue */, RC_LIVE = 4, RC_HEADT = 5 /* + queue */, RC_HEAD = 9 /* + queue */, RC_TAIL = 13 /* + queue */, RC_CHUNK = 17, RC_ABORT = 18, RC_WORDS = 24 };
+// per-launch work statistics (ticks of the 100 MHz wall clock summed over the waves; read by MGYM_LL_ROLL_STATS=1 / tools): cheap enough to stay in
+enum { RS_T_TOTAL = 0, RS_T_SEED, RS_T_CONTACT, RS_N_CONTACT_BATCHES, RS_N_CONTACT_LANES, RS_T_RESET, RS_N_RESET_LANES, RS_T_FREE, RS_N_FREE_STEPS, RS_N_FREE_LANE_STEPS,
+       RS_N_REFILLS, RS_T_IDLE, RS_N_SWITCHES, RS_T_FREE_QUEUE, RS_N_WAVES, RS_T_FREE_BEGIN, RS_T_FREE_SWEEPS, RS_T_FREE_FINISH, RS_T_FREE_ISSUE, RS_N_MAIN, RS_T_LIGHT, RS_N_LIGHT_BATCHES, RS_N_LIGHT_LANES, RS_N_ROTATIONS, RS_COUNT = 24 };
+struct RollStat { unsigned long long v[RS_COUNT]; };
 struct RollQ {
     unsigned long long* ring;   // [RQ_COUNT][cap] slots {sequence << 32 | entry}; slot k starts with sequence k
     uint32_t* ctl;              // [RC_WORDS][32]
     uint32_t mask;              // cap - 1 (cap: a power of two >= n)
     uint32_t K;                 // steps of this launch (<= kRollMaxK)
-    uint32_t contact_min;       // a wave that has other work takes a contact batch only when at least this many entries wait
-    uint32_t refill_min;        // a resident wave refills its vacant lanes only when at least this many are vacant (or none is left)
+    uint32_t contact_min;       // a wave that has other work takes a light-contact batch only when at least this many entries wait
+    uint32_t fair;              // 1: waves serve the queue that is furthest behind (RC_HEADT); 0: fixed order touching contact, light contact, reset, free flight
+    uint32_t heavy_narrow;      // lanes of a touching-contact batch while that queue is BEHIND the free-flight queue (its chain sets the pace then)
+    uint32_t heavy_min, heavy_max;  // ... a touching-contact batch from this many on, of at most this many lanes: K consecutive touching steps of one
+                                // environment are the launch's longest chain, and a batch is as slow as it is wide (more sub-step passes, slower lanes)
+    uint32_t reset_min;         // ... and a reset batch only when at least this many finished environments wait
+    uint32_t free_min;          // ... and goes into free-flight mode only when at least this many entries wait
+    uint32_t refill_min;        // a resident wave refills its vacant lanes only when at least this many are vacant
+    uint32_t residency;         // ... and, while a wave's worth of free-flight entries waits, trades ALL its environments for waiting ones after this many
+                                // steps: the population then advances evenly (entries come out of the ring lowest step index first), and the
+                                // launch does not end with a few late starters taking their K steps one 0.6 ms contact batch at a time
+    unsigned long long* stat;   // [RS_COUNT] (zeroed before every launch)
+    unsigned long long* trace;  // diagnosis (MGYM_LL_ROLL_TRACE=file): [grid][kRollTraceLen] events {ticks since the wave started << 8 | what it begins}; or null
     uint32_t debug;             // diagnosis (MGYM_LL_ROLL_DEBUG): 1 stop after the seed phase, 2 no free-flight mode (every environment through the contact path), 4 resident waves never switch to a contact batch
 };
+constexpr int kRollTraceLen = 512;
+enum { RT_SEED = 1, RT_CONTACT, RT_LIGHT, RT_RESET, RT_FREE, RT_IDLE, RT_END };
 constexpr uint32_t kRollMaxK = 240;          // step index in the top byte of an entry (0xff.. = empty is never a valid entry)
 constexpr uint32_t kRollEnvMask = 0xffffffu;
 constexpr long long kRollTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a wave that waits this long gives up loudly
@@ -60,41 +89,60 @@ LLD void rq_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 LLD bool rq_aborted(const RollQ& q) { return RQ_LOAD(rq_ctl(q, RC_ABORT)) != 0u; }
 LLD void rq_abort(const LLDev& d, const RollQ& q) { atomicOr(rq_ctl(q, RC_ABORT), 1u); atomicOr(d.err, DEV_ERR_INTERNAL); }
 
-// Take up to `want` entries of queue `which` (only if at least `min_avail` wait): wave-uniform result m, lane l < m gets its entry.
-LLD int rq_pop(const LLDev& d, const RollQ& q, int which, int want, int min_avail, uint32_t& ent) {
+// what waits in the four queues and how many environments are still to finish: ONE load instruction (lane w < 5 reads control word w)
+struct RollCounters { int avail[RQ_COUNT]; uint32_t live; int headt[RQ_COUNT]; };
+LLD RollCounters rq_counters(const RollQ& q) {
     const int lane = threadIdx.x & 63;
-    uint32_t h = 0u; int m = 0;
-    if (lane == 0) {
-        for (int tries = 0; tries < 8; ++tries) {
-            h = RQ_LOAD(rq_ctl(q, RC_HEAD + which));
-            const uint32_t t = RQ_LOAD(rq_ctl(q, RC_TAIL + which));
-            const int avail = (int)(t - h);
-            if (avail <= 0 || avail < min_avail) { m = 0; break; }
-            m = avail < want ? avail : want;
-            if (atomicCAS(rq_ctl(q, RC_HEAD + which), h, h + (uint32_t)m) == h) break;
-            m = 0;
-        }
-    }
-    m = __builtin_amdgcn_readfirstlane(m); h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-    ent = 0xffffffffu;
+    uint32_t v = 0u;
+    if (lane < 9) v = RQ_LOAD(rq_ctl(q, lane));
+    RollCounters r;
+    r.headt[0] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 0); r.headt[1] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 1);
+    r.headt[2] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 2); r.headt[3] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 3);
+    r.avail[0] = __builtin_amdgcn_readlane((int)v, 0); r.avail[1] = __builtin_amdgcn_readlane((int)v, 1); r.avail[2] = __builtin_amdgcn_readlane((int)v, 2);
+    r.avail[3] = __builtin_amdgcn_readlane((int)v, 3);
+    r.live = (uint32_t)__builtin_amdgcn_readlane((int)v, RC_LIVE);
+    return r;
+}
+// what a subtraction of `want` from the semaphore (which held `old` before) has really obtained; the rest goes back
+LLD int rq_sem_got(const RollQ& q, int which, int old, int want) {
+    const int got = old <= 0 ? 0 : old < want ? old : want;
+    if (got < want && (threadIdx.x & 63) == 0) atomicAdd(rq_ctl(q, RC_AVAIL + which), (uint32_t)(want - got));
+    return got;
+}
+// the entries at ring positions [h, h + m): lane l < m takes entry h + l out of its slot (waiting, briefly, for a producer that has been
+// handed the position but has not written yet)
+LLD uint32_t rq_take(const LLDev& d, const RollQ& q, int which, uint32_t h, int m) {
+    const int lane = threadIdx.x & 63;
+    uint32_t ent = 0xffffffffu;
     if (lane < m) {
         unsigned long long* const s = rq_slot(q, which, h + (uint32_t)lane);
         const uint32_t want_seq = h + (uint32_t)lane + 1u;
         unsigned long long v = RQ_LOAD(s);
-        if ((uint32_t)(v >> 32) != want_seq) {   // reserved by its producer, not written yet: a few hundred nanoseconds
+        if ((uint32_t)(v >> 32) != want_seq) {
             const long long t0 = wall_clock64();
             do { __builtin_amdgcn_s_sleep(2); v = RQ_LOAD(s); } while ((uint32_t)(v >> 32) != want_seq && wall_clock64() - t0 < kRollTimeoutTicks && !rq_aborted(q));
         }
-        if ((uint32_t)(v >> 32) == want_seq) {
-            ent = (uint32_t)v;
-            RQ_STORE(s, (unsigned long long)(want_seq + q.mask) << 32);   // free for position pos + cap
-        } else {
-            rq_abort(d, q);
-        }
+        if ((uint32_t)(v >> 32) == want_seq) { ent = (uint32_t)v; RQ_STORE(s, (unsigned long long)(want_seq + q.mask) << 32); }   // free for position pos + cap
+        else rq_abort(d, q);
+        if (lane == 0 && ent != 0xffffffffu) RQ_STORE(rq_ctl(q, RC_HEADT + which), ent >> 24);   // how far this queue has got
     }
+    return ent;
+}
+// Take up to `want` entries of queue `which`: wave-uniform result m, lane l < m gets its entry.  Two atomics with a result, one after the other.
+LLD int rq_pop(const LLDev& d, const RollQ& q, int which, int want, uint32_t& ent) {
+    int old = 0;
+    if ((threadIdx.x & 63) == 0) old = (int)atomicSub(rq_ctl(q, RC_AVAIL + which), (uint32_t)want);
+    old = __builtin_amdgcn_readfirstlane(old);
+    const int m = rq_sem_got(q, which, old, want);
+    ent = 0xffffffffu;
+    if (m == 0) return 0;
+    uint32_t h = 0u;
+    if ((threadIdx.x & 63) == 0) h = atomicAdd(rq_ctl(q, RC_HEAD + which), (uint32_t)m);
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    ent = rq_take(d, q, which, h, m);
     return m;
 }
-// Append (wave-aggregated: one atomic per wave).  The caller has made the environment's state visible first (file header).
+// Append (wave-aggregated).  The caller has made the environment's state visible first (file header).
 LLD void rq_push(const LLDev& d, const RollQ& q, int which, bool want, uint32_t ent) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;
@@ -109,10 +157,11 @@ LLD void rq_push(const LLDev& d, const RollQ& q, int which, bool want, uint32_t 
         if ((uint32_t)(RQ_LOAD(s) >> 32) != pos) {   // (the ring holds >= n slots and an environment is queued at most once: its last user is long gone)
             const long long t0 = wall_clock64();
             while ((uint32_t)(RQ_LOAD(s) >> 32) != pos && wall_clock64() - t0 < kRollTimeoutTicks && !rq_aborted(q)) __builtin_amdgcn_s_sleep(2);
-            if ((uint32_t)(RQ_LOAD(s) >> 32) != pos) { rq_abort(d, q); return; }
         }
-        RQ_STORE(s, ((unsigned long long)(pos + 1u) << 32) | ent);
+        if ((uint32_t)(RQ_LOAD(s) >> 32) == pos) RQ_STORE(s, ((unsigned long long)(pos + 1u) << 32) | ent);
+        else rq_abort(d, q);
     }
+    if (lane == leader) atomicAdd(rq_ctl(q, RC_AVAIL + which), (uint32_t)__popcll(mask));   // published (a taker that is faster than the slot store waits at the slot)
 }
 LLD void rq_retire(const RollQ& q, bool want) {
     const unsigned long long mask = __ballot(want);
@@ -219,6 +268,7 @@ struct RollLane {
     bool have;        // an environment lives in this lane
     bool fresh;       // ... and has not been stepped since it was loaded (the record in HBM is its current state)
     uint32_t i, t;    // environment, index of its NEXT step
+    uint32_t act;     // ... and that step's action, fetched a step ahead (before the previous step's outputs are stored: a load behind them waits for them)
     uint32_t seq_word;
     FreeRegs f; EnvRegs e; FreeSolve s;
 };
@@ -244,17 +294,18 @@ LLD void roll_write_scalars(const LLDev& d, const LLIo& io, uint32_t t, uint32_t
 //   RESET  finished and auto-reset is on (also when t1 == K: the reset belongs to step t)
 //   retire t1 == K
 //   FREE / CONTACT by the flag word, as ll_epilogue_kernel classes the next step's population
-enum { ROLL_NONE = 0, ROLL_TO_FREE, ROLL_TO_CONTACT, ROLL_TO_RESET, ROLL_RETIRE };
+enum { ROLL_NONE = 0, ROLL_TO_FREE, ROLL_TO_CONTACT, ROLL_TO_RESET, ROLL_TO_LIGHT, ROLL_RETIRE };
 LLD int roll_route(const LLDev& d, const RollQ& q, uint32_t flags, uint32_t done, uint32_t t1) {
     if (done && d.auto_reset) return ROLL_TO_RESET;
     if (t1 >= q.K) return ROLL_RETIRE;
-    return ll_free_eligible(flags) ? ROLL_TO_FREE : ROLL_TO_CONTACT;
+    return ll_free_eligible(flags) ? ROLL_TO_FREE : (flags & F_TOUCHING) ? ROLL_TO_CONTACT : ROLL_TO_LIGHT;
 }
 LLD void roll_dispatch(const LLDev& d, const RollQ& q, int route, uint32_t i, uint32_t t1) {
     const uint32_t ent = (t1 << 24) | i;
     rq_push(d, q, RQ_FREE, route == ROLL_TO_FREE, ent);
     rq_push(d, q, RQ_CONTACT, route == ROLL_TO_CONTACT, ent);
     rq_push(d, q, RQ_RESET, route == ROLL_TO_RESET, ent);
+    rq_push(d, q, RQ_LIGHT, route == ROLL_TO_LIGHT, ent);
     rq_retire(q, route == ROLL_RETIRE);
 }
 
@@ -404,65 +455,175 @@ __device__ __forceinline__ void roll_reset_batch(const LLDev& d, const LLIo& io,
 
 // ---- free-flight mode: the wave keeps its environments in registers from step to step; leaves when no lane holds one, or when it has
 // taken a contact batch (then its residents are flushed back to the queue first) ----
-// Returns 0 when no lane holds an environment any more, or m > 0: a contact batch of m entries has been claimed and sits in S.late (the residents
-// have been flushed; the caller runs the batch — outside this function, so that the lanes' registers are dead by then)
+// The queue traffic of a step is SOFTWARE-PIPELINED around the 180 sweeps (75 us without a single memory instruction): the atomics that
+// reserve ring positions for the environments that left in the previous step, the claim (compare-and-swap) of free-flight entries for
+// the vacant lanes and the next look at the queues' counters are issued right before the sweeps and their results are used right after
+// them — issued and awaited on the spot they cost 170 us per wave-step with 1 024 waves at the same words (measured), a step 280 us.
+// Returns 0 when no lane holds an environment any more, or m != 0: a contact batch of |m| entries has been taken and sits in S.late (m < 0: from the
+// light queue; the residents have been flushed; the caller runs the batch — outside this function, so that the lanes' registers are dead by then)
+struct RollPending { int route; uint32_t ent; };   // an environment that has left its lane; its record is on its way to memory (written through)
+// issue: ONE atomic instruction reserves the ring positions of all three queues and takes the retiring environments off the live count
+LLD uint32_t roll_dispatch_issue(const RollQ& q, const RollPending& p, unsigned long long (&mask)[5]) {
+    const int lane = threadIdx.x & 63;
+    mask[0] = __ballot(p.route == ROLL_TO_FREE); mask[1] = __ballot(p.route == ROLL_TO_CONTACT); mask[2] = __ballot(p.route == ROLL_TO_RESET);
+    mask[3] = __ballot(p.route == ROLL_TO_LIGHT); mask[4] = __ballot(p.route == ROLL_RETIRE);
+    uint32_t ret = 0u;
+    if (lane < 5) {
+        const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? mask[0] : lane == 1 ? mask[1] : lane == 2 ? mask[2] : lane == 3 ? mask[3] : mask[4]);
+        if (cnt) ret = atomicAdd(lane < 4 ? rq_ctl(q, RC_TAIL + lane) : rq_ctl(q, RC_LIVE), lane < 4 ? cnt : 0u - cnt);
+    }
+    return ret;
+}
+// complete: the entries go into the slots at their ring positions (the caller has waited for the records: rq_drain), then they count as published
+LLD void roll_dispatch_complete(const LLDev& d, const RollQ& q, RollPending& p, const unsigned long long (&mask)[5], uint32_t ret) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int which = 0; which < RQ_COUNT; ++which) {
+        if (mask[which] == 0ull) continue;   // wave-uniform
+        const uint32_t base = __shfl(ret, which);
+        if (p.route == ROLL_TO_FREE + which) {
+            const uint32_t pos = base + (uint32_t)__popcll(mask[which] & ((1ull << lane) - 1ull));
+            unsigned long long* const s = rq_slot(q, which, pos);
+            if ((uint32_t)(RQ_LOAD(s) >> 32) != pos) {
+                const long long t0 = wall_clock64();
+                while ((uint32_t)(RQ_LOAD(s) >> 32) != pos && wall_clock64() - t0 < kRollTimeoutTicks && !rq_aborted(q)) __builtin_amdgcn_s_sleep(2);
+            }
+            if ((uint32_t)(RQ_LOAD(s) >> 32) == pos) RQ_STORE(s, ((unsigned long long)(pos + 1u) << 32) | p.ent);
+            else rq_abort(d, q);
+        }
+    }
+    {   // published: one instruction, up to four words
+        const unsigned long long mine = lane == 0 ? mask[0] : lane == 1 ? mask[1] : lane == 2 ? mask[2] : mask[3];
+        if (lane < RQ_COUNT && mine != 0ull) atomicAdd(rq_ctl(q, RC_AVAIL + lane), (uint32_t)__popcll(mine));
+    }
+    p.route = ROLL_NONE;
+}
+static_assert(ROLL_TO_CONTACT == ROLL_TO_FREE + RQ_CONTACT && ROLL_TO_RESET == ROLL_TO_FREE + RQ_RESET && ROLL_TO_LIGHT == ROLL_TO_FREE + RQ_LIGHT, "routes follow the queue numbers");
+
 template <int BLK>
-__device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, ContactLds<BLK>& S, uint32_t& finished) {
+__device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, ContactLds<BLK>& S, uint32_t& finished, RollStat& st) {
     const int lane = threadIdx.x & 63;
     const PolyTab& tab = S.tab;
     const LLConst& k = LLK(d);
     RollLane L = {};
     L.have = false;
-    for (;;) {
-        // (a) refill vacant lanes from the free-flight queue
-        const unsigned long long vac = __ballot(!L.have);
-        const int n_vac = __popcll(vac);
-        if (n_vac == 64 || n_vac >= (int)q.refill_min) {
-            uint32_t ent;
-            const int m = rq_pop(d, q, RQ_FREE, n_vac, 1, ent);
-            if (m > 0) {
-                // lane l < m holds the entry for the l-th vacant lane: hand them over through LDS
-                if (lane < m) S.late[lane] = ent;
-                __syncthreads();
-                const int rank = __popcll(vac & ((1ull << lane) - 1ull));
-                const bool take = !L.have && rank < m && S.late[rank < m ? rank : 0] != 0xffffffffu;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (take) {
-                    const uint32_t e2 = S.late[rank];
-                    L.i = roll_env_of(e2); L.t = e2 >> 24;
-                    RollRec r;
-                    roll_rec_load(rs, L.i, r);
-                    roll_unpack(d, r, L.f, L.e);
-                    L.seq_word = r.w[C_SEQ];
-                    L.have = true; L.fresh = true;
-                }
-                __syncthreads();
-            }
+    RollPending P; P.route = ROLL_NONE; P.ent = 0u;
+    int f_headt = 0, c_headt = 0, l_headt = 0;
+    int f_avail = 0, c_avail = 0, l_avail = 0;   // what waited in the free-flight / contact / light-contact queues when last looked at (one step ago)
+    uint32_t on_board = 0u;         // steps since the wave last took a full load
+    // take the entries at ring positions [h, h + m) into the vacant lanes: slots -> records (the one exposed round trip of a refill)
+    auto fill = [&](uint32_t h, int m, unsigned long long vac) {
+        const uint32_t ent = rq_take(d, q, RQ_FREE, h, m);
+        __syncthreads();
+        if (lane < m) S.late[lane] = ent;
+        __syncthreads();
+        const int rank = __popcll(vac & ((1ull << lane) - 1ull));
+        const bool take = ((vac >> lane) & 1ull) && rank < m && S.late[rank < m ? rank : 0] != 0xffffffffu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (take) {
+            const uint32_t e2 = S.late[rank];
+            L.i = roll_env_of(e2); L.t = e2 >> 24;
+            RollRec r;
+            roll_rec_load(rs, L.i, r);
+            roll_unpack(d, r, L.f, L.e);
+            L.seq_word = r.w[C_SEQ];
+            L.have = true; L.fresh = true;
+            L.act = io.act[(uint64_t)L.t * d.n + L.i];
         }
-        if (!__any(L.have)) return 0;
-        // (b) does a full contact block wait?  (looked at before the sweeps, acted upon after them)
-        uint32_t c_head = 0u, c_tail = 0u;
-        if (lane == 0) { c_head = RQ_LOAD(rq_ctl(q, RC_HEAD + RQ_CONTACT)); c_tail = RQ_LOAD(rq_ctl(q, RC_TAIL + RQ_CONTACT)); }
-        // (c) one Gym::step of every resident environment
+        __syncthreads();
+    };
+    for (;;) {
+        unsigned long long vac = __ballot(!L.have);
+        if (vac == ~0ull) {   // nobody on board (entering the mode, or everyone has left): finish what is pending, then a refill on the spot
+            if (__any(P.route != ROLL_NONE)) {
+                unsigned long long pm[5];
+                const uint32_t ret = roll_dispatch_issue(q, P, pm);
+                rq_drain();
+                roll_dispatch_complete(d, q, P, pm, ret);
+            }
+            uint32_t ent;
+            const long long tq0 = wall_clock64();
+            const int m = rq_pop(d, q, RQ_FREE, 64, ent);
+            st.v[RS_N_REFILLS] += 1ull;
+            if (m == 0) return 0;
+            // (rq_pop has taken the entries out of their slots already: hand them over as `fill` does)
+            __syncthreads();
+            if (lane < m) S.late[lane] = ent;
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane < m && S.late[lane] != 0xffffffffu) {
+                const uint32_t e2 = S.late[lane];
+                L.i = roll_env_of(e2); L.t = e2 >> 24;
+                RollRec r;
+                roll_rec_load(rs, L.i, r);
+                roll_unpack(d, r, L.f, L.e);
+                L.seq_word = r.w[C_SEQ];
+                L.have = true; L.fresh = true;
+                L.act = io.act[(uint64_t)L.t * d.n + L.i];
+            L.act = io.act[(uint64_t)L.t * d.n + L.i];
+            }
+            __syncthreads();
+            st.v[RS_T_FREE_QUEUE] += (unsigned long long)(wall_clock64() - tq0);
+            f_avail = 0; c_avail = 0; l_avail = 0; on_board = 0u;
+            vac = __ballot(!L.have);
+            if (vac == ~0ull) return 0;
+        }
+        st.v[RS_N_FREE_STEPS] += 1ull; st.v[RS_N_FREE_LANE_STEPS] += (unsigned long long)__popcll(~vac);
+        const long long ts0 = wall_clock64();
+        // (1) one Gym::step of every resident environment: up to the sweeps
         bool run = false, declined = false;
-        uint32_t action = 0u;
         if (L.have) {
-            action = io.act[(uint64_t)L.t * d.n + L.i];
+            const uint32_t action = L.act;
             float d0, d1;
             ll_dispersion(d, L.i, L.e, d0, d1);
             run = ll_free_begin<true>(d, L.i, L.f, L.e, action, d0, d1, L.s);
             declined = !run;   // a pending proxy overlaps the ground (only right after a reset / state import): the contact path, from the record in HBM
         }
+        // (2) queue traffic, issued now and used after the sweeps
+        const long long ts1 = wall_clock64();
+        unsigned long long pm[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+        const bool pushing = __any(P.route != ROLL_NONE);
+        uint32_t push_ret = 0u;
+        if (pushing) push_ret = roll_dispatch_issue(q, P, pm);
+        const int n_vac = __popcll(vac);
+        // ... the semaphore of the free-flight queue, for the vacant lanes, if entries were seen waiting a step ago
+        int claim_want = 0, claim_old = 0;
+        const bool rotate = f_avail >= 64 && on_board + 1u >= q.residency;   // after this step everyone on board makes room for 64 that wait
+        if (rotate) {
+            claim_want = 64;
+            if (lane == 0) claim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + RQ_FREE), (uint32_t)claim_want);
+        } else if (f_avail > 0 && n_vac >= (int)q.refill_min) {
+            claim_want = f_avail < n_vac ? f_avail : n_vac;
+            if (lane == 0) claim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + RQ_FREE), (uint32_t)claim_want);
+        }
+        // ... and the semaphore of the contact queue, if a full block was seen waiting (one attempt per step)
+        int cclaim_want = 0, cclaim_old = 0;
+        // (only a queue that is not AHEAD of the free-flight queue: see RC_HEADT)
+        const int cclaim_which = (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
+                               : (l_avail >= (int)q.contact_min && (!q.fair || f_avail <= 0 || l_headt <= f_headt)) ? RQ_LIGHT : -1;
+        if (cclaim_which >= 0 && !(q.debug & 4u)) {
+            cclaim_want = cclaim_which == RQ_CONTACT ? (c_headt < f_headt ? (int)q.heavy_narrow : (int)q.heavy_max) : BLK;
+            if (lane == 0) cclaim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + cclaim_which), (uint32_t)cclaim_want);
+        }
+        uint32_t seen = 0u;   // next look at the semaphores
+        if (lane < 9) seen = RQ_LOAD(rq_ctl(q, lane));
+        // (3) the 180 velocity sweeps
+        const long long ts2 = wall_clock64();
         for (int it = 0; it < 180; ++it) ll_free_sweep(L.f, k, L.s);
-        int route = ROLL_NONE;
-        bool is_done = false, leave = false;
-        uint32_t ent_t = L.t;
+        // (4) the environments that left in the previous step go into the slots reserved for them
+        const long long tq0 = wall_clock64();
+        st.v[RS_T_FREE_BEGIN] += (unsigned long long)(ts1 - ts0); st.v[RS_T_FREE_ISSUE] += (unsigned long long)(ts2 - ts1); st.v[RS_T_FREE_SWEEPS] += (unsigned long long)(tq0 - ts2);
+        if (pushing) { rq_drain(); roll_dispatch_complete(d, q, P, pm, push_ret); }
+        const long long ts3 = wall_clock64();
+        // (5) the rest of the step; environments that leave their lane become pending
+        bool is_done = false;
         if (run) {
             float state[8], reward; uint32_t done, moved;
             const int how = ll_free_finish<true>(d, L.i, L.f, L.e, tab, L.s, state, reward, done, moved);
             if (how == FREE_DONE) {
                 const uint32_t flags = roll_flags_after_step(L.f, L.e);
-                route = roll_route(d, q, flags, done, L.t + 1u);
+                const int route = roll_route(d, q, flags, done, L.t + 1u);
+                if (route == ROLL_TO_FREE) L.act = io.act[(uint64_t)(L.t + 1u) * d.n + L.i];   // stays on board: next step's action, ahead of this step's stores
                 roll_write_scalars(d, io, L.t, L.i, reward, done);
                 if (route != ROLL_TO_RESET) roll_write_obs(d, io, L.t, L.i, state, L.t + 1u == q.K);
                 is_done = done != 0u;
@@ -471,14 +632,12 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
 #pragma unroll
                 for (int b = 0; b < 3; ++b) { L.f.b[b].force = mk(0.0f, 0.0f); L.f.b[b].torque = 0.0f; }
                 L.t += 1u; L.fresh = false;
-                ent_t = L.t;
                 if (route != ROLL_TO_FREE) {   // the environment leaves the registers: its record goes back, written through
                     RollRec r;
                     roll_pack_store(r, L.f, L.e, flags, L.seq_word);
                     roll_rec_store(rs, L.i, r);
-                    leave = true;
-                } else {
-                    route = ROLL_NONE;        // stays resident
+                    P.route = route; P.ent = (L.t << 24) | L.i;
+                    L.have = false;
                 }
             } else {   // FREE_RESUME: a contact is being created at the end of the step — ≙ ll_free_store_resume, then the contact path finishes step t
                 RollRec r;
@@ -495,37 +654,78 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
                 for (int b = 0; b < 3; ++b)
                     __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(L.f.b[b].sw.c0.x), as_u32(L.f.b[b].sw.c0.y), as_u32(L.f.b[b].sw.a0), as_u32(0.0f)}, rs, off + 16u * b, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(0.0f), 0u, 0u, 0u}, rs, off + 48u, 0, 16);
-                route = ROLL_TO_CONTACT; leave = true;   // same step index: the step is not finished
+                P.route = ROLL_TO_CONTACT; P.ent = (L.t << 24) | L.i;   // same step index: the step is not finished
+                L.have = false;
             }
         } else if (declined) {
             if (!L.fresh) atomicOr(d.err, DEV_ERR_INTERNAL);   // (a stepped environment has no pending proxies)
-            route = ROLL_TO_CONTACT; leave = true;
+            P.route = ROLL_TO_CONTACT; P.ent = (L.t << 24) | L.i;
+            L.have = false;
         }
         finished += (uint32_t)__popcll(__ballot(is_done));
-        if (__any(leave)) {
-            rq_drain();   // the written-through records have arrived
-            roll_dispatch(d, q, route, L.i, ent_t);
-            if (leave) L.have = false;
+        const long long ts4 = wall_clock64();
+        st.v[RS_T_FREE_FINISH] += (unsigned long long)(ts4 - ts3);
+        // (6) what the free-flight semaphore has granted: ring positions for it, then fill the lanes that were vacant before the sweeps
+        if (claim_want > 0) {
+            st.v[RS_N_REFILLS] += 1ull;
+            const int got = rq_sem_got(q, RQ_FREE, __builtin_amdgcn_readfirstlane(claim_old), claim_want);
+            if (got > 0) {
+                uint32_t h = 0u;
+                if (lane == 0) h = atomicAdd(rq_ctl(q, RC_HEAD + RQ_FREE), (uint32_t)got);
+                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+                if (rotate) {   // everyone still on board goes back to the queue (record written through if it was stepped here) ...
+                    if (L.have) {
+                        if (!L.fresh) {
+                            RollRec r;
+                            roll_pack_store(r, L.f, L.e, L.f.flags, L.seq_word);
+                            roll_rec_store(rs, L.i, r);
+                        }
+                        P.route = ROLL_TO_FREE; P.ent = (L.t << 24) | L.i;
+                        L.have = false;
+                    }
+                    on_board = 0u;
+                    st.v[RS_N_ROTATIONS] += 1ull;
+                }
+                fill(h, got, rotate ? ~0ull : vac);   // ... and the waiting ones come on board
+            }
         }
-        // (d) a full contact block waits: take it (one wave wins the claim), flush the residents, run it, come back
-        c_head = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_head); c_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_tail);
-        if ((int)(c_tail - c_head) >= (int)q.contact_min && !(q.debug & 4u)) {
-            uint32_t ent;
-            const int m = rq_pop(d, q, RQ_CONTACT, BLK, (int)q.contact_min, ent);
+        on_board += 1u;
+        f_avail = __builtin_amdgcn_readlane((int)seen, RQ_FREE); c_avail = __builtin_amdgcn_readlane((int)seen, RQ_CONTACT); l_avail = __builtin_amdgcn_readlane((int)seen, RQ_LIGHT);
+        f_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_FREE); c_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_CONTACT); l_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_LIGHT);
+        st.v[RS_T_FREE_QUEUE] += (unsigned long long)((wall_clock64() - ts4) + (ts3 - tq0));
+        // (7) what the contact semaphore has granted: everyone leaves the registers, the batch goes to the caller
+        if (cclaim_want > 0) {
+            const int m = rq_sem_got(q, cclaim_which, __builtin_amdgcn_readfirstlane(cclaim_old), cclaim_want);
             if (m > 0) {
+                uint32_t h = 0u;
+                if (lane == 0) h = atomicAdd(rq_ctl(q, RC_HEAD + cclaim_which), (uint32_t)m);
+                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+                const uint32_t ent = rq_take(d, q, cclaim_which, h, m);
+                // the pending ones are joined by the residents (their records written through if they have been stepped here)
+                unsigned long long pm2[5];
+                if (__any(P.route != ROLL_NONE)) {
+                    const uint32_t ret = roll_dispatch_issue(q, P, pm2);
+                    rq_drain();
+                    roll_dispatch_complete(d, q, P, pm2, ret);
+                }
                 if (L.have) {
                     if (!L.fresh) {
                         RollRec r;
                         roll_pack_store(r, L.f, L.e, L.f.flags, L.seq_word);
                         roll_rec_store(rs, L.i, r);
                     }
+                    P.route = ROLL_TO_FREE; P.ent = (L.t << 24) | L.i;
                 }
-                rq_drain();
-                rq_push(d, q, RQ_FREE, L.have, (L.t << 24) | L.i);
+                {
+                    const uint32_t ret = roll_dispatch_issue(q, P, pm2);
+                    rq_drain();
+                    roll_dispatch_complete(d, q, P, pm2, ret);
+                }
                 __syncthreads();
                 if (lane < m) S.late[lane] = ent;
                 __syncthreads();
-                return m;
+                st.v[RS_N_SWITCHES] += 1ull;
+                return cclaim_which == RQ_LIGHT ? -m : m;
             }
         }
     }
@@ -539,6 +739,15 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
     const int lane = threadIdx.x & 63;
     uint32_t overflow = 0u, finished = 0u;
     bool not_reset = false;
+    RollStat st = {};
+    const long long t_begin = wall_clock64();
+    int n_trace = 0, last_kind = 0;
+    auto trace = [&](int kind) {   // (what the wave begins now; consecutive events of one kind are recorded once)
+        if (q.trace && kind != last_kind && n_trace < kRollTraceLen && lane == 0)
+            q.trace[(uint64_t)blockIdx.x * kRollTraceLen + n_trace] = ((unsigned long long)(wall_clock64() - t_begin) << 8) | (unsigned long long)kind;
+        if (kind != last_kind) { ++n_trace; last_kind = kind; }
+    };
+    trace(RT_SEED);
     stage_tab(S.tab, LLK(d));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.st, 0, 0xffffffff, 0x00020000);
     VConstraint* const far_lane0 = d.vc_far + (uint64_t)blockIdx.x * BLK;
@@ -563,50 +772,77 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
                 }
                 route = ROLL_RETIRE;
             } else {
-                route = ll_free_eligible(flags) ? ROLL_TO_FREE : ROLL_TO_CONTACT;
+                route = ll_free_eligible(flags) ? ROLL_TO_FREE : (flags & F_TOUCHING) ? ROLL_TO_CONTACT : ROLL_TO_LIGHT;
             }
         }
         roll_dispatch(d, q, route, (uint32_t)i, 0u);
     }
+    st.v[RS_T_SEED] = (unsigned long long)(wall_clock64() - t_begin);
     if (q.debug & 1u) { ll_report(d, not_reset, overflow, finished); return; }   // (diagnosis: the seed phase alone)
     // serve the queues until every environment has done its K steps
     long long idle_since = -1;
     for (;;) {
-        uint32_t ent = 0xffffffffu;
-        bool is_reset = false, in_late = false;
-        int m = rq_pop(d, q, RQ_CONTACT, BLK, (int)q.contact_min, ent);
-        if (m == 0) { m = rq_pop(d, q, RQ_RESET, BLK, 1, ent); is_reset = m > 0; }
-        if (m == 0 && !(q.debug & 2u)) {
-            const uint32_t fh = (uint32_t)__builtin_amdgcn_readfirstlane((int)RQ_LOAD(rq_ctl(q, RC_HEAD + RQ_FREE)));
-            const uint32_t ft = (uint32_t)__builtin_amdgcn_readfirstlane((int)RQ_LOAD(rq_ctl(q, RC_TAIL + RQ_FREE)));
-            if ((int)(ft - fh) > 0) {
-                m = roll_free_mode<BLK>(d, io, q, rs, S, finished);   // -> a contact batch it has claimed (in S.late), or 0
-                idle_since = -1;
-                if (m == 0) continue;
-                in_late = true;
-            }
+        const long long t_look = wall_clock64();
+        const RollCounters c = rq_counters(q);
+        const int aF = c.avail[RQ_FREE], aC = c.avail[RQ_CONTACT], aR = c.avail[RQ_RESET], aL = c.avail[RQ_LIGHT];
+        // the queue that is furthest behind among those with a batch's worth of entries (ties: touching contact, light contact, reset, free flight);
+        // with nothing like that, any entries at all by the same rule
+        int which = -1, best_t = 0x7fffffff;
+        const int order[RQ_COUNT] = {RQ_CONTACT, RQ_LIGHT, RQ_RESET, RQ_FREE};
+        const int need[RQ_COUNT] = {(int)q.free_min, (int)q.heavy_min, (int)q.reset_min, (int)q.contact_min};   // by queue number
+#pragma unroll
+        for (int o = 0; o < RQ_COUNT; ++o) { const int w = order[o]; const int ht = q.fair ? c.headt[w] : o; if (c.avail[w] >= need[w] && ht < best_t) { which = w; best_t = ht; } }
+        if (which < 0) {
+#pragma unroll
+            for (int o = 0; o < RQ_COUNT; ++o) { const int w = order[o]; const int ht = q.fair ? c.headt[w] : o; if (c.avail[w] > 0 && ht < best_t) { which = w; best_t = ht; } }
         }
-        if (m == 0 && (q.debug & 2u)) m = rq_pop(d, q, RQ_FREE, BLK, 1, ent);   // (diagnosis: every environment through the contact path)
-        if (m == 0) m = rq_pop(d, q, RQ_CONTACT, BLK, 1, ent);                    // nothing else to do: a partial block
-        if (m > 0) {
-            if (!in_late) {
-                __syncthreads();
-                if (lane < m) S.late[lane] = ent;
-                __syncthreads();
-            }
-            if (is_reset) roll_reset_batch<BLK>(d, io, q, m, S);
-            else roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished);
+        const int heavy_lanes = c.headt[RQ_CONTACT] < c.headt[RQ_FREE] ? (int)q.heavy_narrow : (int)q.heavy_max;
+        (void)aF; (void)aC; (void)aR; (void)aL;
+        int m = 0;
+        if (which == RQ_FREE && !(q.debug & 2u)) {
+            const long long tf0 = wall_clock64();
+            trace(RT_FREE);
+            m = roll_free_mode<BLK>(d, io, q, rs, S, finished, st);   // -> a contact batch it has taken (in S.late), or 0
+            st.v[RS_T_FREE] += (unsigned long long)(wall_clock64() - tf0);
+            idle_since = -1;
+            if (m == 0) { st.v[RS_N_MAIN] += 1ull; continue; }
+            which = m < 0 ? RQ_LIGHT : RQ_CONTACT;
+            m = m < 0 ? -m : m;
+        } else if (which >= 0) {
+            uint32_t ent;
+            m = rq_pop(d, q, which, which == RQ_CONTACT ? heavy_lanes : BLK, ent);
+            if (m == 0) { st.v[RS_N_MAIN] += 1ull; continue; }   // others were faster: look again
             __syncthreads();
+            if (lane < m) S.late[lane] = ent;
+            __syncthreads();
+        }
+        if (which >= 0) {
+            const long long tb0 = wall_clock64();
+            trace(which == RQ_RESET ? RT_RESET : which == RQ_LIGHT ? RT_LIGHT : RT_CONTACT);
+            if (which == RQ_RESET) roll_reset_batch<BLK>(d, io, q, m, S);
+            else roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished);   // (diagnosis 2: free-flight entries come here too)
+            __syncthreads();
+            const unsigned long long tb = (unsigned long long)(wall_clock64() - tb0);
+            if (which == RQ_RESET) { st.v[RS_T_RESET] += tb; st.v[RS_N_RESET_LANES] += (unsigned long long)m; }
+            else if (which == RQ_LIGHT) { st.v[RS_T_LIGHT] += tb; st.v[RS_N_LIGHT_BATCHES] += 1ull; st.v[RS_N_LIGHT_LANES] += (unsigned long long)m; }
+            else { st.v[RS_T_CONTACT] += tb; st.v[RS_N_CONTACT_BATCHES] += 1ull; st.v[RS_N_CONTACT_LANES] += (unsigned long long)m; }
             idle_since = -1;
             continue;
         }
-        const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)RQ_LOAD(rq_ctl(q, RC_LIVE)));
-        if (live == 0u || rq_aborted(q)) break;
+        if (c.live == 0u || rq_aborted(q)) break;
+        trace(RT_IDLE);
         const long long now = wall_clock64();
         if (idle_since < 0) idle_since = now;
         else if (now - idle_since > kRollTimeoutTicks) { if (lane == 0) rq_abort(d, q); break; }
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(100);
+        st.v[RS_T_IDLE] += (unsigned long long)(wall_clock64() - t_look);
     }
+    trace(RT_END);
+    st.v[RS_T_TOTAL] = (unsigned long long)(wall_clock64() - t_begin); st.v[RS_N_WAVES] = 1ull;
+    if (lane < RS_COUNT && q.stat) { unsigned long long mine = 0ull;
+#pragma unroll
+        for (int z = 0; z < RS_COUNT; ++z) mine = lane == z ? st.v[z] : mine;
+        if (mine) atomicAdd(q.stat + lane, mine); }
     ll_report(d, not_reset, overflow, finished);
 }
 
@@ -620,6 +856,8 @@ __global__ void ll_rollout_ring_init_kernel(RollQ q) {
 // before every launch: the chunk counter, the number of environments still to finish, the abort word (the rings carry on where the last launch left them)
 __global__ void ll_rollout_begin_kernel(RollQ q, uint32_t n) {
     if (threadIdx.x == 0) { *rq_ctl(q, RC_CHUNK) = 0u; *rq_ctl(q, RC_LIVE) = n; *rq_ctl(q, RC_ABORT) = 0u; }
+    if (threadIdx.x < RQ_COUNT) *rq_ctl(q, RC_HEADT + threadIdx.x) = 0u;
+    if (threadIdx.x < RS_COUNT && q.stat) q.stat[threadIdx.x] = 0ull;
 }
 
 }  // namespace mgym

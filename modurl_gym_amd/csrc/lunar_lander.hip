@@ -28,6 +28,8 @@
 // orders (counter memsets + ll_classify_kernel per step, select / copy launches, sequential kernels, follow-up TOI launches): profiling.
 // MGYM_LL_STAGED_RESET=0 computes a reset when the episode ends instead of preparing it ahead.
 #include <math.h>
+#include <stdio.h>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1050,12 +1052,14 @@ struct LunarLanderEnv final : Env {
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
     // mgym_rollout as ONE persistent launch (ll_roll.h); MGYM_LL_ROLLOUT=0: K x step()
-    int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : 0;   // (off by default until it is faster than K x step())
+    int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : 1;
+    int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : 8;   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
     void* roll_ring = nullptr;
     void* roll_ctl = nullptr;
     void* roll_vc_far = nullptr;
     RollQ rq{};
     unsigned roll_grid = 0;
+    void* roll_trace = nullptr;
 
     ~LunarLanderEnv() override {
         if (base) (void)hipFree(base);
@@ -1066,6 +1070,7 @@ struct LunarLanderEnv final : Env {
         if (roll_ring) (void)hipFree(roll_ring);
         if (roll_ctl) (void)hipFree(roll_ctl);
         if (roll_vc_far) (void)hipFree(roll_vc_far);
+        if (roll_trace) (void)hipFree(roll_trace);
         if (aux) (void)hipStreamDestroy(aux);
         if (env_class) (void)hipFree(env_class);
         if (aux2) { (void)hipStreamSynchronize(aux2); (void)hipStreamDestroy(aux2); }
@@ -1173,10 +1178,22 @@ struct LunarLanderEnv final : Env {
             while (cap < n) cap <<= 1;
             rq.mask = (uint32_t)(cap - 1);
             MGYM_HIP(hipMalloc(&roll_ring, (size_t)cap * RQ_COUNT * sizeof(unsigned long long)));
-            MGYM_HIP(hipMalloc(&roll_ctl, (size_t)RC_WORDS * 32 * sizeof(uint32_t)));
+            MGYM_HIP(hipMalloc(&roll_ctl, (size_t)RC_WORDS * 32 * sizeof(uint32_t) + RS_COUNT * sizeof(unsigned long long)));
             rq.ring = static_cast<unsigned long long*>(roll_ring);
             rq.ctl = static_cast<uint32_t*>(roll_ctl);
+            rq.stat = reinterpret_cast<unsigned long long*>(rq.ctl + RC_WORDS * 32);
             rq.contact_min = getenv("MGYM_LL_ROLL_CONTACT_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_CONTACT_MIN")) : 32u;
+            rq.heavy_min = getenv("MGYM_LL_ROLL_HEAVY_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_MIN")) : 16u;
+            rq.heavy_max = getenv("MGYM_LL_ROLL_HEAVY_MAX") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_MAX")) : 32u;
+            if (rq.heavy_max > 32u) rq.heavy_max = 32u;
+            if (rq.heavy_max < 1u) rq.heavy_max = 1u;
+            rq.fair = getenv("MGYM_LL_ROLL_FAIR") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_FAIR")) : 0u;
+            rq.heavy_narrow = getenv("MGYM_LL_ROLL_HEAVY_NARROW") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_NARROW")) : 12u;
+            if (rq.heavy_narrow > rq.heavy_max) rq.heavy_narrow = rq.heavy_max;
+            if (rq.heavy_narrow < 1u) rq.heavy_narrow = 1u;
+            rq.reset_min = getenv("MGYM_LL_ROLL_RESET_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_RESET_MIN")) : 16u;
+            rq.free_min = getenv("MGYM_LL_ROLL_FREE_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_FREE_MIN")) : 32u;
+            rq.residency = getenv("MGYM_LL_ROLL_RESIDENCY") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_RESIDENCY")) : 2u;
             rq.refill_min = getenv("MGYM_LL_ROLL_REFILL_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_REFILL_MIN")) : 8u;
             rq.debug = getenv("MGYM_LL_ROLL_DEBUG") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_DEBUG")) : 0u;
             hipLaunchKernelGGL(ll_rollout_ring_init_kernel, dim3(256), dim3(256), 0, stream, rq);
@@ -1194,12 +1211,16 @@ struct LunarLanderEnv final : Env {
             roll_grid = (unsigned)g;
             const size_t per_lane = (size_t)(kSolverCap - vc_near_limit);
             MGYM_HIP(hipMalloc(&roll_vc_far, per_lane * (size_t)roll_grid * 32 * sizeof(VConstraint)));
+            if (getenv("MGYM_LL_ROLL_TRACE")) {   // diagnosis: what every wave did when (written to that file after each launch; synchronises)
+                MGYM_HIP(hipMalloc(&roll_trace, (size_t)roll_grid * kRollTraceLen * sizeof(unsigned long long)));
+                rq.trace = static_cast<unsigned long long*>(roll_trace);
+            }
         }
         return MGYM_OK;
     }
     // K steps of every environment in ONE persistent launch (ll_roll.h): identical per-environment results to K calls of step()
     int rollout(const void* actions, int K, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
-        if (!roll_enabled || n == 0 || K <= 0) return Env::rollout(actions, K, obs_out, reward, done, trunc);
+        if (!roll_enabled || n == 0 || K < roll_min_k) return Env::rollout(actions, K, obs_out, reward, done, trunc);
         int st = join_helpers();
         if (st != MGYM_OK) return st;
         LLDev rd = dev; rd.split = 0;
@@ -1209,8 +1230,31 @@ struct LunarLanderEnv final : Env {
             LLIo io{static_cast<const uint32_t*>(actions) + (size_t)k0 * n, obs_out ? obs_out + (size_t)k0 * 8 * n : nullptr, reward ? reward + (size_t)k0 * n : nullptr,
                     done ? done + (size_t)k0 * n : nullptr, trunc ? trunc + (size_t)k0 * n : nullptr};
             RollQ q = rq; q.K = (uint32_t)kc;
+            if (roll_trace) MGYM_HIP(hipMemsetAsync(roll_trace, 0, (size_t)roll_grid * kRollTraceLen * sizeof(unsigned long long), stream));
             hipLaunchKernelGGL(ll_rollout_begin_kernel, dim3(1), dim3(64), 0, stream, q, (uint32_t)n);
             hipLaunchKernelGGL(ll_rollout_kernel<32>, dim3(roll_grid), dim3(64), 0, stream, rd, io, q);
+        }
+        if (roll_trace) {
+            std::vector<unsigned long long> h((size_t)roll_grid * kRollTraceLen);
+            MGYM_HIP(hipStreamSynchronize(stream));
+            MGYM_HIP(hipMemcpy(h.data(), roll_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(getenv("MGYM_LL_ROLL_TRACE"), "wb")) { const unsigned hdr[2] = {roll_grid, (unsigned)kRollTraceLen}; fwrite(hdr, sizeof hdr, 1, f); fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+        }
+        if (getenv("MGYM_LL_ROLL_STATS")) {   // diagnosis: where the waves of the last launch spent their time (synchronises)
+            unsigned long long h[RS_COUNT];
+            MGYM_HIP(hipStreamSynchronize(stream));
+            MGYM_HIP(hipMemcpy(h, rq.stat, sizeof h, hipMemcpyDeviceToHost));
+            const double w = h[RS_N_WAVES] ? (double)h[RS_N_WAVES] : 1.0, us = 0.01;
+            auto per = [&](int t, int nn) { return h[nn] ? h[t] * us / h[nn] : 0.0; };
+            fprintf(stderr, "ll_rollout K=%d waves=%.0f: per wave us: total %.0f seed %.0f | touching-contact %.0f (%.1f batches of %.1f lanes, %.0f us each) | light-contact %.0f (%.1f batches of %.1f lanes, %.0f us each) | "
+                            "reset %.0f (%.1f lanes) | free %.0f (%.1f steps of %.1f lanes, %.1f us each: begin %.1f issue %.1f sweeps %.1f finish %.1f queue %.1f; %.1f refills %.1f switches %.1f rotations) | idle %.0f, %.1f looks without work\n",
+                    K, w, h[RS_T_TOTAL] * us / w, h[RS_T_SEED] * us / w,
+                    h[RS_T_CONTACT] * us / w, h[RS_N_CONTACT_BATCHES] / w, h[RS_N_CONTACT_BATCHES] ? (double)h[RS_N_CONTACT_LANES] / h[RS_N_CONTACT_BATCHES] : 0.0, per(RS_T_CONTACT, RS_N_CONTACT_BATCHES),
+                    h[RS_T_LIGHT] * us / w, h[RS_N_LIGHT_BATCHES] / w, h[RS_N_LIGHT_BATCHES] ? (double)h[RS_N_LIGHT_LANES] / h[RS_N_LIGHT_BATCHES] : 0.0, per(RS_T_LIGHT, RS_N_LIGHT_BATCHES),
+                    h[RS_T_RESET] * us / w, h[RS_N_RESET_LANES] / w,
+                    h[RS_T_FREE] * us / w, h[RS_N_FREE_STEPS] / w, h[RS_N_FREE_STEPS] ? (double)h[RS_N_FREE_LANE_STEPS] / h[RS_N_FREE_STEPS] : 0.0, per(RS_T_FREE, RS_N_FREE_STEPS),
+                    per(RS_T_FREE_BEGIN, RS_N_FREE_STEPS), per(RS_T_FREE_ISSUE, RS_N_FREE_STEPS), per(RS_T_FREE_SWEEPS, RS_N_FREE_STEPS), per(RS_T_FREE_FINISH, RS_N_FREE_STEPS), per(RS_T_FREE_QUEUE, RS_N_FREE_STEPS),
+                    h[RS_N_REFILLS] / w, h[RS_N_SWITCHES] / w, h[RS_N_ROTATIONS] / w, h[RS_T_IDLE] * us / w, h[RS_N_MAIN] / w);
         }
         if (staged) direct_possible = true;   // episodes that ended inside the launch were reset there: their prepared successors no longer fit
         if (fused_tail) { st = rebuild_list(); if (st != MGYM_OK) return st; }
@@ -1394,9 +1438,12 @@ struct LunarLanderEnv final : Env {
                 const unsigned g_contact = gb, g_free = free2_grid(), g_prep = stage1 ? 128u : 0u;
                 hipLaunchKernelGGL(ll_step_kernel<32>, dim3(g_contact + g_free + g_prep), dim3(64), 0, stream, sd, sh, io, g_contact, g_free);
                 LLIo rio1{nullptr, obs_out, nullptr, nullptr, nullptr};
+                // A step that is being CAPTURED always carries the two (normally empty) direct-reset launches: whether a finished env will
+                // find a fitting prepared episode is decided when the graph RUNS — after a later mgym_set_state, say — not now.
+                const bool direct_now = direct_possible || capturing();
                 if (stage1) {
-                    hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio1, 1, direct_possible ? 1 : 0);
-                    if (direct_possible) launch_resets(rio1, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
+                    hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio1, 1, direct_now ? 1 : 0);
+                    if (direct_now) launch_resets(rio1, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
                 } else {
                     if (dev.auto_reset) launch_resets(rio1, false);
                     if (dev.auto_reset && staged) direct_possible = true;   // resets computed here leave no prepared successor behind
@@ -1427,8 +1474,9 @@ struct LunarLanderEnv final : Env {
             if (stage) {
                 int st = join_helpers();
                 if (st != MGYM_OK) return st;
-                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1, direct_possible ? 1 : 0);
-                if (direct_possible) launch_resets(rio, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
+                const bool direct_now = direct_possible || capturing();   // (see the single-launch order above)
+                hipLaunchKernelGGL(ll_epilogue_kernel, dim3(classify_grid()), dim3(1024), 0, stream, dev, (const uint32_t*)shadow_base, (const float*)shadow_obs, rio, 1, direct_now ? 1 : 0);
+                if (direct_now) launch_resets(rio, false, L_RESET_DIRECT, true);   // (two launches, normally empty)
                 st = mark_prepare(cap);
                 if (st != MGYM_OK) return st;
             } else {
@@ -1497,7 +1545,9 @@ struct LunarLanderEnv final : Env {
     // mgym_get_info: the launch structure of this handle and whether its streams really run side by side
     int info(std::string& out) override {
         out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
-               "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) + "\n";
+               "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) +
+               "\nrollout=" + (roll_enabled ? "persistent_launch" : "k_steps") + "\nrollout_min_k=" + std::to_string(roll_min_k) + "\nrollout_waves=" + std::to_string(roll_grid) + "\n";
+        if (capturing()) { set_last_error("mgym_get_info: the stream is being captured (the call launches probe kernels and synchronises)"); return MGYM_ERR_BAD_ARG; }
         hipStream_t ss[3] = {stream, aux, aux2};
         const int ns = aux2 ? 3 : 2;
         unsigned long long* d_t = nullptr;
@@ -1506,10 +1556,12 @@ struct LunarLanderEnv final : Env {
         MGYM_HIP(hipStreamSynchronize(aux));
         if (aux2) MGYM_HIP(hipStreamSynchronize(aux2));
         MGYM_HIP(hipMalloc((void**)&d_t, sizeof h_t));
+        hipError_t perr = hipSuccess;
         for (int q = 0; q < ns; ++q) hipLaunchKernelGGL(ll_queue_probe_kernel, dim3(1), dim3(1), 0, ss[q], d_t + 2 * q, 5000ull);  // 50 us each
-        for (int q = 0; q < ns; ++q) MGYM_HIP(hipStreamSynchronize(ss[q]));
-        MGYM_HIP(hipMemcpy(h_t, d_t, sizeof h_t, hipMemcpyDeviceToHost));
-        MGYM_HIP(hipFree(d_t));
+        for (int q = 0; q < ns && perr == hipSuccess; ++q) perr = hipStreamSynchronize(ss[q]);
+        if (perr == hipSuccess) perr = hipMemcpy(h_t, d_t, sizeof h_t, hipMemcpyDeviceToHost);
+        (void)hipFree(d_t);   // (also on the error paths)
+        MGYM_HIP(perr);
         // the largest set of probes whose intervals share an instant: count the intervals covering each start time
         int best = 1;
         for (int a = 0; a < ns; ++a) {
@@ -1536,6 +1588,7 @@ struct LunarLanderEnv final : Env {
     }
     int set_dispersion(const float* disp) override {
         direct_possible = true;
+        if (disp != dev.disp) ++config_epoch;   // the dispersion source is a kernel argument: graphs captured under the other one are refused (abi.hip)
         if (staged) {  // states prepared under the other dispersion source no longer fit: episode 0 never equals a live counter + 1
             int st = join_helpers();
             if (st != MGYM_OK) return st;

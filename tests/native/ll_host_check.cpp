@@ -30,6 +30,8 @@ static unsigned g_ptrace[60][9]; static unsigned long g_pcycle_at[62], g_pcycle_
     if (at_ == 61 && g_ptrace_print > 0) { --g_ptrace_print; printf("-- island position solve that ran out without repeating (%d contacts):\n", (int)(count)); for (int q_ = 0; q_ < 60; q_ += (q_ < 4 || q_ >= 54) ? 1 : 10) { printf("   %2d:", q_); for (int z_ = 0; z_ < 9; ++z_) printf(" %08x", g_ptrace[q_][z_]); printf("\n"); } } } \
     g_pos_iters[kind][(count) < 12 ? (count) : 12][(iters)]++; g_pos_how[kind][(solved)]++; } while (0)
 #define LL_POS_ITER_STAT_OLD(kind, count, iters, solved) do { g_pos_iters[kind][(count) < 12 ? (count) : 12][(iters)]++; g_pos_how[kind][(solved)]++; } while (0)
+static unsigned long g_free_pos[62]; static int g_free_pos_wave_max; static unsigned long g_free_pos_wavehist[62];
+#define LL_FREE_POS_STAT(iters) do { g_free_pos[(iters)]++; if ((iters) > g_free_pos_wave_max) g_free_pos_wave_max = (iters); } while (0)
 #define LL_TOI_SWEEP_TRACE(done, cur, count) do { for (int z_ = 0; z_ < 11; ++z_) g_trace[(done) - 1][z_] = (cur).w[z_]; } while (0)
 #endif
 #include "../../modurl_gym_amd/csrc/ll_free.h"
@@ -95,6 +97,9 @@ int main(int argc, char** argv) {
         ora_vec_step(ov, act.data(), oobs.data(), orew.data(), odone.data(), otr.data(), 1);
         for (uint64_t i = 0; i < n; ++i) {
             float state[8], reward, d0, d1; uint32_t done;
+#ifdef LL_HOST_STATS
+            if ((i & 63u) == 0u) { if (i) g_free_pos_wavehist[g_free_pos_wave_max]++; g_free_pos_wave_max = 0; }
+#endif
             // same dispatch as ll_free_kernel / ll_general_kernel: fast path when eligible and it accepts
             bool fast = false;
             if (ll_free_eligible(ST(C_FLAGS))) {
@@ -170,6 +175,12 @@ int main(int argc, char** argv) {
     for (int q = 0; q < 8; ++q) printf(" %lu", round_hist[q]);
     printf("\n");
 #ifdef LL_HOST_STATS
+    { unsigned long tot = 0, sum = 0; for (int q = 0; q < 62; ++q) { tot += g_free_pos[q]; sum += g_free_pos[q] * (q > 60 ? 60 : q); }
+      printf("free-flight steps %lu: joint position iterations mean %.2f; histogram 1..10:", tot, (double)sum / (tot ? tot : 1)); for (int q = 1; q <= 10; ++q) printf(" %.2f%%", 100.0 * g_free_pos[q] / (tot ? tot : 1));
+      unsigned long m20 = 0, m60 = 0; for (int q = 11; q < 62; ++q) { if (q <= 20) m20 += g_free_pos[q]; else m60 += g_free_pos[q]; } printf("  11-20: %.3f%%  21-60+: %.3f%% (ran out: %.3f%%)\n", 100.0 * m20 / (tot ? tot : 1), 100.0 * m60 / (tot ? tot : 1), 100.0 * g_free_pos[61] / (tot ? tot : 1));
+      unsigned long wt = 0, ws = 0; for (int q = 0; q < 62; ++q) { wt += g_free_pos_wavehist[q]; ws += g_free_pos_wavehist[q] * (q > 60 ? 60 : q); }
+      printf("   maximum over each group of 64 consecutive envs (what a wave runs): mean %.1f; histogram 0..12:", (double)ws / (wt ? wt : 1)); for (int q = 0; q <= 12; ++q) printf(" %.1f%%", 100.0 * g_free_pos_wavehist[q] / (wt ? wt : 1));
+      unsigned long w60 = 0; for (int q = 13; q < 62; ++q) w60 += g_free_pos_wavehist[q]; printf("  13+: %.1f%% (60: %.1f%%)\n", 100.0 * w60 / (wt ? wt : 1), 100.0 * (g_free_pos_wavehist[60] + g_free_pos_wavehist[61]) / (wt ? wt : 1)); }
     for (int tq = 0; tq < 2; ++tq) { unsigned long tot = 0, sum = 0; for (int r = 0; r < 6; ++r) { tot += g_rounds_by_touch[tq][r]; sum += g_rounds_by_touch[tq][r] * r; }
         printf("general steps that start %s a touching contact: %lu; sub-steps 0/1/2/3/4/5+:", tq ? "with" : "without", tot); for (int r = 0; r < 6; ++r) printf(" %.1f%%", 100.0 * g_rounds_by_touch[tq][r] / (tot ? tot : 1)); printf("  mean %.2f\n", (double)sum / (tot ? tot : 1)); }
     for (int c = 0; c < 9; ++c) { unsigned long tot = 0, sum = 0; for (int r = 0; r < 6; ++r) { tot += g_rounds_by_ncont[c][r]; sum += g_rounds_by_ncont[c][r] * r; }
