@@ -57,6 +57,10 @@ struct RollQ {
     uint32_t mask;              // cap - 1 (cap: a power of two >= n)
     uint32_t K;                 // steps of this launch (<= kRollMaxK)
     uint32_t contact_min;       // a wave that has other work takes a light-contact batch only when at least this many entries wait
+    uint32_t tail_live, tail_lanes;  // once fewer environments than tail_live are still to finish, waves idle anyway: batches of at most tail_lanes lanes
+                                // (a batch is as slow as it is wide, and what remains is a chain of batches)
+    uint32_t keep_min;          // ... as long as at least this many are on board after the refill
+    uint32_t keep;              // bit 0: touching-contact batches keep the environments that stay in their class (roll_contact_batch), bit 1: light ones too
     uint32_t fair;              // 1: waves serve the queue that is furthest behind (RC_HEADT); 0: fixed order touching contact, light contact, reset, free flight
     uint32_t heavy_narrow;      // lanes of a touching-contact batch while that queue is BEHIND the free-flight queue (its chain sets the pace then)
     uint32_t heavy_min, heavy_max;  // ... a touching-contact batch from this many on, of at most this many lanes: K consecutive touching steps of one
@@ -309,105 +313,158 @@ LLD void roll_dispatch(const LLDev& d, const RollQ& q, int route, uint32_t i, ui
     rq_retire(q, route == ROLL_RETIRE);
 }
 
-// ---- contact batch: `m` entries in S.late, one per lane; the body of ll_contact_body<BLK> for one pass with a step index per lane ----
+// ---- contact batch: `m` entries in S.late, one per lane; the body of ll_contact_body<BLK> for one pass with a step index per lane.
+// keep_which >= 0 (the queue the entries came from): an environment that ends its step in the SAME class stays in its lane for its next
+// step — its record goes through memory as always (ll_store / ll_load by the same lane: nothing to publish, nothing to acquire) but not
+// through the queue — and lanes that fall vacant are refilled from that queue, up to max_lanes on board.  K consecutive touching steps
+// of one environment are the launch's longest chain: this takes the queue hand-over (a wave in free-flight mode looks at the queues once
+// per step) out of every link of it.
 template <int BLK>
 __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& io, const RollQ& q, int m, ContactLds<BLK>& S, VConstraint* far_lane0, int far_stride,
-                                                   uint32_t& overflow, uint32_t& finished) {
+                                                   uint32_t& overflow, uint32_t& finished, int keep_which, int max_lanes, unsigned long long& n_batches, unsigned long long& n_lanes) {
     static_assert(BLK <= 32, "rollout: World records in LDS");
     constexpr int kThreads = ll_contact_threads(BLK);
     const PolyTab& tab = S.tab;
     const bool env_lane = threadIdx.x < BLK;
     const int own = env_lane ? (int)threadIdx.x : 0;
+    const int lane = threadIdx.x & 63;
     const CtHot hot{(LL_LDS uint32_t*)S.hot + own, (uint32_t)BLK, 1u};
     PConstraint l_pc[kSolverCap];
     CSolverMem mem;
     mem.vc = &S.vc[own]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNearLds ? d.vc_near : kVcNearLds; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     mem.vc_far = far_lane0 + own; mem.vc_far_stride = far_stride;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the records were last written by other compute units, in this launch
-    const bool have = env_lane && (int)threadIdx.x < m && S.late[threadIdx.x] != 0xffffffffu;   // (an entry is only missing after a timeout: the launch is being aborted)
-    uint32_t i = 0u, t = 0u, action = 0u;
-    bool stepping = false, islanding = false;
-    int n_refresh = 0;
-    World& w = S.world[own];
-    EnvRegs e;
+    bool have = env_lane && (int)threadIdx.x < m && S.late[threadIdx.x] != 0xffffffffu;   // (an entry is only missing after a timeout: the launch is being aborted)
+    uint32_t i = 0u, t = 0u;
+    if (have) { const uint32_t ent = S.late[threadIdx.x]; i = roll_env_of(ent); t = ent >> 24; }
     if (q.debug & 8u) { rq_retire(q, have); return; }   // (diagnosis: the batch framing alone)
-    if (have) {
-        const uint32_t ent = S.late[threadIdx.x];
-        i = roll_env_of(ent); t = ent >> 24;
-        w.t = (LL_LDS WorldTmp*)S.tmp + own;
-        ll_load(d, i, w, e, hot);
-    }
-    if (q.debug & 16u) { if (have && e.step == 0xfffffff0u) atomicOr(d.err, DEV_ERR_INTERNAL); rq_retire(q, have); return; }   // (diagnosis: ... and the load)
-    if (have) {
-        action = io.act[(uint64_t)t * d.n + i];
-        if (w.resume) {   // the free-flight path has taken this step up to the end of the island solve (ll_free.h)
-            ll_resume_after_island(w);
-        } else {
-            float d0, d1, m_power, s_power;
-            ll_dispersion(d, i, e, d0, d1);
-            ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
-            n_refresh = world_step_pre(w); islanding = true;                                          // world.step, :1066: Collide's list walk
+    bool fresh = true;   // entries have come out of the queue since the last acquire
+    for (;;) {
+        if (fresh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // their records were last written by other compute units, in this launch
+        n_batches += 1ull; n_lanes += (unsigned long long)__popcll(__ballot(have));
+        uint32_t action = 0u;
+        bool stepping = false, islanding = false;
+        int n_refresh = 0;
+        World& w = S.world[own];
+        EnvRegs e;
+        if (have) {
+            w.t = (LL_LDS WorldTmp*)S.tmp + own;
+            ll_load(d, i, w, e, hot);
         }
-        stepping = true;
-    }
-    {   // b2ContactManager::Collide: the wave's manifold refreshes dealt out over all 64 lanes (see ll_contact_body)
-        int incl = n_refresh;
-        for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
-        const int n_tasks = __shfl(incl, 63);
-        if (n_tasks > 0) {   // wave-uniform
-            const int offs = incl - n_refresh;
-            for (int j = 0; j < n_refresh; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
-            __syncthreads();
-            constexpr int kHelpRoom = (int)(sizeof(S.vc) / (2 * kMaxPoly * sizeof(V2)));
-            constexpr int kExec = BLK + ((kThreads - BLK) < kHelpRoom ? (kThreads - BLK) : kHelpRoom);
-            V2* const poly_tmp = env_lane ? (V2*)((LL_LDS WorldTmp*)S.tmp + own)->poly_tmp : (V2*)S.vc + (size_t)(threadIdx.x - BLK) * (2 * kMaxPoly);
-            if ((int)threadIdx.x < kExec)
-                for (int tk = (int)threadIdx.x; tk < n_tasks; tk += kExec) {
-                    const uint32_t task = S.task[tk];
-                    collide_refresh(S.world[task >> 4], tab, (int)(task & 15u), poly_tmp);
-                }
-            __syncthreads();
+        if (q.debug & 16u) { if (have && e.step == 0xfffffff0u) atomicOr(d.err, DEV_ERR_INTERNAL); rq_retire(q, have); return; }   // (diagnosis: ... and the load)
+        if (have) {
+            action = io.act[(uint64_t)t * d.n + i];
+            if (w.resume) {   // the free-flight path has taken this step up to the end of the island solve (ll_free.h)
+                ll_resume_after_island(w);
+            } else {
+                float d0, d1, m_power, s_power;
+                ll_dispersion(d, i, e, d0, d1);
+                ll_pre_step(w.b[0], w.legs[0], w.legs[1], e, LLK(d), action, d0, d1, m_power, s_power);   // wind / engines, :926-1048
+                n_refresh = world_step_pre(w); islanding = true;                                          // world.step, :1066: Collide's list walk
+            }
+            stepping = true;
         }
-        if (islanding) world_step_island(w, tab, LLK(d), mem);   // the callbacks of Collide, then b2World::Solve
-    }
-    {   // b2World::SolveTOI, passes in lock step over the wave, time-of-impact evaluations dealt out over all 64 lanes
-        ToiLoop L;
-        bool running = stepping && toi_begin(w, L, true);
-        int budget = -1;
-        while (__any(running)) {   // wave-uniform
-            const int n_need = running ? toi_list(w, L) : 0;
-            int incl = n_need;
+        {   // b2ContactManager::Collide: the wave's manifold refreshes dealt out over all 64 lanes (see ll_contact_body)
+            int incl = n_refresh;
             for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
             const int n_tasks = __shfl(incl, 63);
-            const int offs = incl - n_need;
-            for (int j = 0; j < n_need; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
-            __syncthreads();
-            for (int tk = (int)threadIdx.x; tk < n_tasks; tk += kThreads) {
-                const uint32_t task = S.task[tk];
-                toi_evaluate(S.world[task >> 4], tab, (int)(task & 15u));
+            if (n_tasks > 0) {   // wave-uniform
+                const int offs = incl - n_refresh;
+                for (int j = 0; j < n_refresh; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
+                __syncthreads();
+                constexpr int kHelpRoom = (int)(sizeof(S.vc) / (2 * kMaxPoly * sizeof(V2)));
+                constexpr int kExec = BLK + ((kThreads - BLK) < kHelpRoom ? (kThreads - BLK) : kHelpRoom);
+                V2* const poly_tmp = env_lane ? (V2*)((LL_LDS WorldTmp*)S.tmp + own)->poly_tmp : (V2*)S.vc + (size_t)(threadIdx.x - BLK) * (2 * kMaxPoly);
+                if ((int)threadIdx.x < kExec)
+                    for (int tk = (int)threadIdx.x; tk < n_tasks; tk += kExec) {
+                        const uint32_t task = S.task[tk];
+                        collide_refresh(S.world[task >> 4], tab, (int)(task & 15u), poly_tmp);
+                    }
+                __syncthreads();
             }
-            __syncthreads();
-            if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
+            if (islanding) world_step_island(w, tab, LLK(d), mem);   // the callbacks of Collide, then b2World::Solve
+        }
+        {   // b2World::SolveTOI, passes in lock step over the wave, time-of-impact evaluations dealt out over all 64 lanes
+            ToiLoop L;
+            bool running = stepping && toi_begin(w, L, true);
+            int budget = -1;
+            while (__any(running)) {   // wave-uniform
+                const int n_need = running ? toi_list(w, L) : 0;
+                int incl = n_need;
+                for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
+                const int n_tasks = __shfl(incl, 63);
+                const int offs = incl - n_need;
+                for (int j = 0; j < n_need; ++j) S.task[offs + j] = (uint16_t)(((uint32_t)own << 4) | ((LL_LDS WorldTmp*)S.tmp + own)->idx[1][j]);
+                __syncthreads();
+                for (int tk = (int)threadIdx.x; tk < n_tasks; tk += kThreads) {
+                    const uint32_t task = S.task[tk];
+                    toi_evaluate(S.world[task >> 4], tab, (int)(task & 15u));
+                }
+                __syncthreads();
+                if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
+            }
+        }
+        int route = ROLL_NONE;
+        bool is_done = false;
+        if (stepping) {
+            float state[8], reward; uint32_t done;
+            ll_step_finish(w, e, action, state, reward, done);
+            const uint32_t flags = (q.debug & (32u | 256u)) ? (F_HAS_WORLD | 7u) : ll_store(d, i, w, e);
+            route = (q.debug & (32u | 128u)) ? ROLL_RETIRE : roll_route(d, q, flags, (q.debug & 256u) ? 0u : done, t + 1u);
+            if (!(q.debug & 64u)) roll_write_scalars(d, io, t, i, reward, done);
+            if (route != ROLL_TO_RESET && !(q.debug & 64u)) roll_write_obs(d, io, t, i, state, t + 1u == q.K);   // (a finished env's observation comes from its reset)
+            is_done = done != 0u;
+            overflow |= w.overflow;
+        }
+        finished += (uint32_t)__popcll(__ballot(is_done));
+        const bool stay = keep_which >= 0 && route == ROLL_TO_FREE + keep_which;   // same class again: the next step right here
+        if (stay) route = ROLL_NONE;
+        if (__any(route != ROLL_NONE)) {   // make the stored records visible to whoever takes the environments next, then queue them
+            rq_drain();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            rq_drain();
+            roll_dispatch(d, q, route, i, t + 1u);
+        }
+        if (keep_which < 0) return;
+        have = stay;
+        t += 1u;
+        // vacant lanes: more of the same kind, if any wait
+        fresh = false;
+        const unsigned long long vac = __ballot(env_lane && !have);
+        const int on_board = __popcll(__ballot(have));
+        const int room = (max_lanes < BLK ? max_lanes : BLK) - on_board;
+        if (room > 0) {
+            int avail = 0;
+            if (lane == 0) avail = (int)RQ_LOAD(rq_ctl(q, RC_AVAIL + keep_which));
+            avail = __builtin_amdgcn_readfirstlane(avail);
+            if (avail > 0) {
+                uint32_t ent;
+                const int mm = rq_pop(d, q, keep_which, room < avail ? room : avail, ent);
+                if (mm > 0) {
+                    __syncthreads();
+                    if (lane < mm) S.late[lane] = ent;
+                    __syncthreads();
+                    const int rank = __popcll(vac & ((1ull << lane) - 1ull));
+                    if (env_lane && !have && rank < mm && S.late[rank] != 0xffffffffu) {
+                        const uint32_t e2 = S.late[rank];
+                        i = roll_env_of(e2); t = e2 >> 24;
+                        have = true;
+                    }
+                    __syncthreads();
+                    fresh = true;
+                }
+            }
+        }
+        if (!__any(have)) return;
+        // too few on board for a batch of its own: they go back to the queue, where they meet others (narrow batches cost the machine as much time
+        // as wide ones: with every wave keeping its survivors the batches thinned out to 8 lanes, measured)
+        if (__popcll(__ballot(have)) < (int)q.keep_min && !(__builtin_amdgcn_readfirstlane((int)RQ_LOAD(rq_ctl(q, RC_LIVE))) < (int)q.tail_live)) {
+            rq_drain();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            rq_drain();
+            roll_dispatch(d, q, have ? ROLL_TO_FREE + keep_which : ROLL_NONE, i, t);
+            return;
         }
     }
-    int route = ROLL_NONE;
-    bool is_done = false;
-    if (stepping) {
-        float state[8], reward; uint32_t done;
-        ll_step_finish(w, e, action, state, reward, done);
-        const uint32_t flags = (q.debug & (32u | 256u)) ? (F_HAS_WORLD | 7u) : ll_store(d, i, w, e);
-        route = (q.debug & (32u | 128u)) ? ROLL_RETIRE : roll_route(d, q, flags, (q.debug & 256u) ? 0u : done, t + 1u);
-        if (!(q.debug & 64u)) roll_write_scalars(d, io, t, i, reward, done);
-        if (route != ROLL_TO_RESET && !(q.debug & 64u)) roll_write_obs(d, io, t, i, state, t + 1u == q.K);   // (a finished env's observation comes from its reset)
-        is_done = done != 0u;
-        overflow |= w.overflow;
-    }
-    finished += (uint32_t)__popcll(__ballot(is_done));
-    // make the stored records visible to whoever takes the environments next, then queue them
-    rq_drain();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    rq_drain();
-    roll_dispatch(d, q, route, i, t + 1u);
 }
 
 // ---- reset batch: reset() of up to BLK finished environments — the scene (lunar_lander.rs:727-908), then the implicit step(0) on the
@@ -789,14 +846,15 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
         // with nothing like that, any entries at all by the same rule
         int which = -1, best_t = 0x7fffffff;
         const int order[RQ_COUNT] = {RQ_CONTACT, RQ_LIGHT, RQ_RESET, RQ_FREE};
-        const int need[RQ_COUNT] = {(int)q.free_min, (int)q.heavy_min, (int)q.reset_min, (int)q.contact_min};   // by queue number
+        const int need[RQ_COUNT] = {(int)q.free_min, c.live < q.tail_live ? 1 : (int)q.heavy_min, c.live < q.tail_live ? 1 : (int)q.reset_min, c.live < q.tail_live ? 1 : (int)q.contact_min};   // by queue number
 #pragma unroll
         for (int o = 0; o < RQ_COUNT; ++o) { const int w = order[o]; const int ht = q.fair ? c.headt[w] : o; if (c.avail[w] >= need[w] && ht < best_t) { which = w; best_t = ht; } }
         if (which < 0) {
 #pragma unroll
             for (int o = 0; o < RQ_COUNT; ++o) { const int w = order[o]; const int ht = q.fair ? c.headt[w] : o; if (c.avail[w] > 0 && ht < best_t) { which = w; best_t = ht; } }
         }
-        const int heavy_lanes = c.headt[RQ_CONTACT] < c.headt[RQ_FREE] ? (int)q.heavy_narrow : (int)q.heavy_max;
+        const bool tail = c.live < q.tail_live;
+        const int heavy_lanes = tail ? (int)q.tail_lanes : c.headt[RQ_CONTACT] < c.headt[RQ_FREE] ? (int)q.heavy_narrow : (int)q.heavy_max;
         (void)aF; (void)aC; (void)aR; (void)aL;
         int m = 0;
         if (which == RQ_FREE && !(q.debug & 2u)) {
@@ -810,7 +868,7 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
             m = m < 0 ? -m : m;
         } else if (which >= 0) {
             uint32_t ent;
-            m = rq_pop(d, q, which, which == RQ_CONTACT ? heavy_lanes : BLK, ent);
+            m = rq_pop(d, q, which, which == RQ_CONTACT ? heavy_lanes : (tail && which == RQ_LIGHT) ? (int)q.tail_lanes : BLK, ent);
             if (m == 0) { st.v[RS_N_MAIN] += 1ull; continue; }   // others were faster: look again
             __syncthreads();
             if (lane < m) S.late[lane] = ent;
@@ -820,12 +878,13 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
             const long long tb0 = wall_clock64();
             trace(which == RQ_RESET ? RT_RESET : which == RQ_LIGHT ? RT_LIGHT : RT_CONTACT);
             if (which == RQ_RESET) roll_reset_batch<BLK>(d, io, q, m, S);
-            else roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished);   // (diagnosis 2: free-flight entries come here too)
+            else if (which == RQ_LIGHT) roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished, (q.keep & 2u) ? RQ_LIGHT : -1, tail ? (int)q.tail_lanes : BLK, st.v[RS_N_LIGHT_BATCHES], st.v[RS_N_LIGHT_LANES]);
+            else roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished, (which == RQ_CONTACT && (q.keep & 1u)) ? RQ_CONTACT : -1, heavy_lanes, st.v[RS_N_CONTACT_BATCHES], st.v[RS_N_CONTACT_LANES]);   // (diagnosis 2: free-flight entries come here too)
             __syncthreads();
             const unsigned long long tb = (unsigned long long)(wall_clock64() - tb0);
             if (which == RQ_RESET) { st.v[RS_T_RESET] += tb; st.v[RS_N_RESET_LANES] += (unsigned long long)m; }
-            else if (which == RQ_LIGHT) { st.v[RS_T_LIGHT] += tb; st.v[RS_N_LIGHT_BATCHES] += 1ull; st.v[RS_N_LIGHT_LANES] += (unsigned long long)m; }
-            else { st.v[RS_T_CONTACT] += tb; st.v[RS_N_CONTACT_BATCHES] += 1ull; st.v[RS_N_CONTACT_LANES] += (unsigned long long)m; }
+            else if (which == RQ_LIGHT) st.v[RS_T_LIGHT] += tb;
+            else st.v[RS_T_CONTACT] += tb;
             idle_since = -1;
             continue;
         }

@@ -1187,6 +1187,12 @@ struct LunarLanderEnv final : Env {
             rq.heavy_max = getenv("MGYM_LL_ROLL_HEAVY_MAX") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_MAX")) : 32u;
             if (rq.heavy_max > 32u) rq.heavy_max = 32u;
             if (rq.heavy_max < 1u) rq.heavy_max = 1u;
+            rq.tail_live = getenv("MGYM_LL_ROLL_TAIL_LIVE") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_TAIL_LIVE")) : 32768u;
+            rq.tail_lanes = getenv("MGYM_LL_ROLL_TAIL_LANES") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_TAIL_LANES")) : 4u;
+            if (rq.tail_lanes > 32u) rq.tail_lanes = 32u;
+            if (rq.tail_lanes < 1u) rq.tail_lanes = 1u;
+            rq.keep_min = getenv("MGYM_LL_ROLL_KEEP_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_KEEP_MIN")) : 24u;
+            rq.keep = getenv("MGYM_LL_ROLL_KEEP") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_KEEP")) : 1u;
             rq.fair = getenv("MGYM_LL_ROLL_FAIR") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_FAIR")) : 0u;
             rq.heavy_narrow = getenv("MGYM_LL_ROLL_HEAVY_NARROW") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_NARROW")) : 12u;
             if (rq.heavy_narrow > rq.heavy_max) rq.heavy_narrow = rq.heavy_max;
