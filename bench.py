@@ -247,6 +247,15 @@ def lunar_roofline(n, step_s):
         out["frac_if_all_64_lanes_counted"] = rec["f32_flop_per_step_lanes64"] / step_s / 157.3e12
         out["traffic"] = rec.get("hbm_bytes_per_step")   # FETCH_SIZE x2 + WRITE_SIZE summed over the step's launches (the bound is VALU: for reference)
         out["counter_source"] = rec.get("source")
+        # why the fraction is what it is, from the same counter records (dominant kernel of the step)
+        dom = max(rec.get("kernels", {}).items(), key=lambda kv: (kv[1].get("avg_ns") or 0) * kv[1].get("launches_per_step", 1), default=(None, None))
+        if dom[0]:
+            out["dominant_kernel"] = dom[0]
+            for k_out, k_in in (("active_lanes_per_valu_inst", "mean_active_lanes"), ("valu_busy_share_of_wave_cycles", "valu_busy_share_of_wave_cycles"),
+                                ("wait_share", "wait_any_share_of_wave_cycles"), ("waves_per_simd", "waves_per_simd"), ("scratch_bytes_per_lane", "scratch_bytes_per_lane"),
+                                ("vgprs", "vgprs"), ("lds_bytes_per_block", "lds_bytes_per_block")):
+                if dom[1].get(k_in) is not None:
+                    out[k_out] = dom[1][k_in]
     return out
 
 
@@ -460,6 +469,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             m_err = repr(e)
         barrier()
+        m_el_roll = -1.0
         if m_err is None:
             try:
                 t0 = time.perf_counter()
@@ -469,18 +479,43 @@ def main():
                 m_el = time.perf_counter() - t0
                 for st in mst:
                     st.env.sync()
+                # the same mixed batch with LunarLander stepped through mgym_rollout (K = 16: the action ring IS a [16][n] table), CartPole and
+                # MountainCar as before; a persistent LunarLander launch holds every SIMD, so the other two families run between the launches
+                ll = next(st for st in mst if st.name == "lunar_lander")
+                rw = torch.empty((RING, ll.n), device=f"cuda:{local_rank}", dtype=torch.float32)
+                dn = torch.zeros((RING, ll.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+                tr = torch.zeros((RING, ll.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+                torch.cuda.synchronize()
+                ll.env.rollout_device(ll.actions, RING, None, rw, dn, tr)   # (untimed first call)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for st in mst:
+                    if st is ll:
+                        for _ in range(msteps // RING):
+                            ll.env.rollout_device(ll.actions, RING, None, rw, dn, tr)
+                    else:
+                        st.run(msteps)
+                torch.cuda.synchronize()
+                m_el_roll = time.perf_counter() - t0
+                for st in mst:
+                    st.env.sync()
                     st.close()
             except Exception as e:  # noqa: BLE001
-                m_err, m_el = repr(e), -1.0
+                m_err, m_el, m_el_roll = repr(e), -1.0, -1.0
         if dist is not None:
-            t = torch.tensor([m_el, -m_el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([m_el, -m_el, m_el_roll, -m_el_roll], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             m_el = float(t[0]) if float(t[1]) < 0 else -1.0   # any rank failing (its -m_el = +1) voids the figure
+            m_el_roll = float(t[2]) if float(t[3]) < 0 else -1.0
         if m_el > 0:
             mixed_rec = {"env_steps_per_s": (1 << 20) * world * msteps / m_el, "ms_per_step": 1e3 * m_el / msteps,
                          "n_envs_total": (1 << 20) * world, "n_gpus": world, "steps": msteps, "warmup": mwarm,
                          "per_gpu": "524288 CartPole + 262144 MountainCar + 262144 LunarLander (wind on), fused auto-reset, one stream per family",
                          "scaling": "weak", "note": "max over ranks, barrier before; LunarLander dominates the step time"}
+            if m_el_roll > 0:
+                mixed_rec["lunar_lander_through_mgym_rollout_K16"] = {"env_steps_per_s": (1 << 20) * world * msteps / m_el_roll, "ms_per_step": 1e3 * m_el_roll / msteps,
+                                                                      "note": "same batch, LunarLander stepped by mgym_rollout (K = 16 per launch: one persistent launch in which environments advance "
+                                                                              "independently), CartPole and MountainCar by graph-replayed mgym_step"}
         else:
             mixed_rec = {"error": m_err or "failed on another rank"}
 
@@ -533,6 +568,28 @@ def main():
                     del src, dst
             if wl == "lunar_lander":
                 rec["roofline"] = lunar_roofline(cnt, ms * 1e-3 / k)
+                # mgym_rollout: K steps in ONE persistent launch in which every environment advances as soon as it is ready (SURVEY §8f-1;
+                # modurl_gym_amd/csrc/ll_roll.h) — same handle, same steady population, the same per-environment results as K mgym_step calls
+                for K_roll, reps in ((8, 6), (16, 4), (64, 2)):
+                    acts_k = torch.randint(0, 4, (K_roll, cnt), device=f"cuda:{local_rank}", dtype=torch.int32)
+                    rw = torch.empty((K_roll, cnt), device=f"cuda:{local_rank}", dtype=torch.float32)
+                    dn = torch.zeros((K_roll, cnt), device=f"cuda:{local_rank}", dtype=torch.uint8)
+                    tr = torch.zeros((K_roll, cnt), device=f"cuda:{local_rank}", dtype=torch.uint8)
+                    stream.wait_stream(torch.cuda.current_stream(local_rank))
+                    st.env.rollout_device(acts_k, K_roll, None, rw, dn, tr)   # (first call: untimed)
+                    st.env.sync()
+                    st.env.timer_start()
+                    for _ in range(reps):
+                        st.env.rollout_device(acts_k, K_roll, None, rw, dn, tr)
+                    rms = st.env.timer_stop()
+                    st.env.sync()
+                    extra[f"lunar_lander_rollout_K{K_roll}"] = {
+                        "env_steps_per_s": cnt * K_roll * reps / (rms * 1e-3), "us_per_step": rms * 1e3 / (K_roll * reps), "n_envs": cnt, "steps": K_roll * reps,
+                        "launches_per_rollout": 2, "vs_mgym_step": (ms / k) / (rms / (K_roll * reps)),
+                        "note": "mgym_rollout: one persistent launch per K steps, environments advance independently through device queues; "
+                                "word-for-word equal to K mgym_step calls (tests/test_gpu_lunar_rollout.py); the launch ends with its last environments' chains, "
+                                "so longer rollouts amortise better"}
+                    del acts_k, rw, dn, tr
             extra[name] = rec
             st.close()
         # fused K-step rollout (mgym_rollout): same semantics as K steps, state stays in registers
@@ -553,6 +610,56 @@ def main():
         extra["cartpole_rollout_K16"] = {"env_steps_per_s": st.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps, "n_envs": st.n,
                                          "steps": ksteps, "alg_bytes_per_env_step": 10 + 40 / RING,
                                          "note": "mgym_rollout: K=16 steps per launch, bit-identical to 16 mgym_step calls"}
+        st.close()
+        # BASELINE configs[2] as SURVEY §8d C3 defines it: MountainCar-v0 and MountainCarContinuous-v0, 1 048 576 envs each, separate handles on
+        # separate streams, both in flight at once (graph replay on each stream, common start, the later end counts)
+        s_a, s_b = stream, torch.cuda.Stream(device=local_rank)
+        pa = Stepper(mg, torch, "mountain_car", 1 << 20, local_rank, args.seed + 13, 0, s_a, args.reset, "graph")
+        pb = Stepper(mg, torch, "mountain_car_cont", 1 << 20, local_rank, args.seed + 14, 0, s_b, args.reset, "graph")
+        pair_steps = 25 * RING
+        for p_ in (pa, pb):
+            p_.build_timed_graph(pair_steps)    # ONE graph of pair_steps launches per handle: two hipGraphLaunch calls in all
+            p_.run(2 * RING)
+            p_.env.sync()
+        torch.cuda.synchronize()
+        e_go, e_a, e_b = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e_go.record(s_a)
+        s_b.wait_event(e_go)
+        pa.run_timed(pair_steps)
+        pb.run_timed(pair_steps)
+        e_a.record(s_a)
+        e_b.record(s_b)
+        torch.cuda.synchronize()
+        pms = max(e_go.elapsed_time(e_a), e_go.elapsed_time(e_b))
+        pa.env.sync(), pb.env.sync()
+        pair_bytes = (ALG_BYTES["mountain_car"] + ALG_BYTES["mountain_car_cont"]) * (1 << 20)
+        extra["mountain_car_pair"] = {
+            "env_steps_per_s": 2 * (1 << 20) * pair_steps / (pms * 1e-3), "us_per_step_of_both": pms * 1e3 / pair_steps, "n_envs": 2 << 20, "steps": pair_steps,
+            "roofline": {"bound": "hbm", "achieved": pair_bytes * pair_steps / (pms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": pair_bytes * pair_steps / (pms * 1e-3) / HBM_PEAK, "traffic": None, "alg_bytes_in_flight_per_step": pair_bytes,
+                         "kernel": "mountaincar_step4_kernel<false, true> beside mountaincar_step4_kernel<true, true>"},
+            "note": "MountainCar-v0 + MountainCarContinuous-v0, 1 048 576 envs each, two handles on two streams, graph-replayed at once; time from the common start "
+                    "to the later stream's end"}
+        pa.close(), pb.close()
+        # fused K-step rollout for MountainCar (table form of mgym_rollout: the state stays in registers across the K steps)
+        st = Stepper(mg, torch, "mountain_car", 1 << 20, local_rank, args.seed + 15, 0, stream, "fused", "eager")
+        rw = torch.empty((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.float32)
+        dn = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        tr = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        stream.wait_stream(torch.cuda.current_stream(local_rank))
+        for _ in range(4):
+            st.env.rollout_device(st.actions, RING, None, rw, dn, tr)
+        st.env.sync()
+        st.env.timer_start()
+        reps = 50
+        for _ in range(reps):
+            st.env.rollout_device(st.actions, RING, None, rw, dn, tr)
+        ms = st.env.timer_stop()
+        st.env.sync()
+        ksteps = reps * RING
+        extra["mountain_car_rollout_K16"] = {"env_steps_per_s": st.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps, "n_envs": st.n, "steps": ksteps,
+                                             "alg_bytes_per_env_step": 10 + 16 / RING,
+                                             "note": "mgym_rollout: K=16 steps per launch (action 4 R + reward 4 W + flags 2 W per step, state 8 R + 8 W per launch), bit-identical to 16 mgym_step calls"}
         st.close()
         # the step either side of the path: a torch policy produces the actions on the same
         # stream, the engine steps, the next observation feeds the policy — no host synchronisation in the loop

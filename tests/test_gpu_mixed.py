@@ -71,3 +71,45 @@ def test_config5_per_gpu_population_matches_oracle_with_global_ids():
             assert np.array_equal(got[0][:, o:o + 512], eo), f"lunar_lander step {t} block {o}: observation"
             episodes += int(ed.sum())
     assert episodes > 1000   # crashes / landings with contacts and resets happened in the checked blocks
+
+
+def test_bench_steppers_in_graph_mode_on_three_streams_equal_the_oracles():
+    """The figure `extra.mixed_configs4_this_n` comes from bench.py's own Stepper objects — one per family, each on a stream of its own,
+    every step a hipGraph replay of 16 captured step launches with the fused auto-reset (LunarLander: staged resets inside the graph).
+    This drives exactly those objects (smaller populations, same code) and compares the engines' final state blobs and finished-episode
+    counts with oracles fed the same action ring.  Protocol: /root/reference src/testing.rs:65-134 (step, compare, reset when done)."""
+    import torch
+
+    import bench
+
+    steps = 160    # 10 replays of the 16-step graph; long enough for LunarLander contacts, crashes and fused resets
+    pop = {"cartpole": 65536, "mountain_car": 32768, "lunar_lander": 32768}
+    kinds = {"cartpole": (ora.CARTPOLE, {}), "mountain_car": (ora.MOUNTAINCAR, {}), "lunar_lander": (ora.LUNARLANDER, dict(enable_wind=True))}
+    streams = [torch.cuda.Stream(device=0) for _ in pop]
+    base, steppers = 0, []
+    for (name, cnt), st in zip(pop.items(), streams):
+        steppers.append(bench.Stepper(mg, torch, name, cnt, 0, SEED, base + RANK * cnt, st, "fused", "auto"))
+        base += WORLD * cnt
+    assert all(s.launch == "graph" for s in steppers)
+    for s in steppers:          # issue order of bench.py's mixed section: every family's replays queued, the streams overlap on the device
+        s.run(steps)
+    torch.cuda.synchronize()
+    for s in steppers:
+        s.env.sync()
+    base = 0
+    for s, (name, cnt) in zip(steppers, pop.items()):
+        okind, extra = kinds[name]
+        ref = ora.OracleVec(okind, cnt, seed=SEED, env_id_base=base + RANK * cnt, **extra)
+        base += WORLD * cnt
+        ref.reset(nthreads=16)
+        ring = s.actions.cpu().numpy().astype(np.uint32)
+        finished = 0
+        for k in range(steps):
+            _, _, d, tr = ref.step(ring[k % bench.RING], nthreads=16)
+            m = (d | tr).astype(np.uint8)
+            finished += int(m.sum())
+            ref.reset(mask=m, nthreads=16)
+        assert np.array_equal(s.env.get_state().view(np.uint32), ref.get_state().view(np.uint32)), f"{name}: state blob after {steps} graph-replayed steps"
+        assert s.env.episode_count() == finished and (finished > 0 or name == "mountain_car"), name   # (a random policy never drives the car up the hill)
+    for s in steppers:
+        s.close()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "modurl_gym_amd", "csrc")
 SRC = {"cartpole": ["cartpole.hip", "cartpole_step.h", "cartpole_math.h", "mgym_math.h", "philox.h", "common.h"],
        "mountain_car": ["mountain_car.hip", "mgym_math.h", "philox.h", "common.h"],
-       "lunar_lander": ["lunar_lander.hip", "ll_env.h", "ll_free.h", "ll_world.h", "ll_b2.h", "mgym_math.h", "philox.h", "common.h"]}
+       "lunar_lander": ["lunar_lander.hip", "ll_roll.h", "ll_env.h", "ll_free.h", "ll_world.h", "ll_b2.h", "mgym_math.h", "philox.h", "common.h"]}
 
 
 def sha16(files):
@@ -56,7 +56,11 @@ def main():
                 hbm += (d.get("fetch_bytes_x2", 0.0) + d.get("write_bytes", 0.0)) * per_step
                 per[k.split("(")[0].replace("void mgym::", "")] = {"avg_ns": v.get("avg_ns_steady"), "launches_per_step": per_step, "f32_flop_lanes64": f64, "f32_flop_active_lanes": act,
                                                                    "mean_active_lanes": d.get("mean_active_lanes_per_valu_inst"),
-                                                                   "valu_busy_share_of_wave_cycles": d.get("valu_active_share_of_wave_cycles")}
+                                                                   "valu_busy_share_of_wave_cycles": d.get("valu_active_share_of_wave_cycles"),
+                                                                   "wait_any_share_of_wave_cycles": (v["pmc"]["SQ_WAIT_ANY"] / v["pmc"]["SQ_WAVE_CYCLES"]) if v["pmc"].get("SQ_WAVE_CYCLES") else None,
+                                                                   "vgprs": v.get("launch", {}).get("vgpr"), "scratch_bytes_per_lane": v.get("launch", {}).get("scratch"),
+                                                                   "lds_bytes_per_block": v.get("launch", {}).get("lds"),
+                                                                   "waves_per_simd": (1 if (v.get("launch", {}).get("vgpr") or 0) > 128 else 2 if (v.get("launch", {}).get("vgpr") or 0) > 96 else None)}
             rec.update(f32_flop_per_step_lanes64=lanes64, f32_flop_per_step_active_lanes=active, hbm_bytes_per_step=hbm, kernels=per,
                        note="per step (launches_per_step x the per-launch average; the kernels of one step overlap in time); flop = 64 x (2 x SQ_INSTS_VALU_FMA_F32 + MUL_F32 + ADD_F32), weighted by "
                             "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (mean active lanes per VALU instruction) for the active-lane figure")
