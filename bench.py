@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --envs (default: BASELINE size) per GPU; strong: --total-envs fixed for the node, index-sharded over the ranks")
     ap.add_argument("--total-envs", type=int, default=8 << 20, help="node total for --scaling strong (default 8 388 608, BASELINE configs[4])")
+    ap.add_argument("--ll-rollout", type=int, default=0, metavar="K",
+                    help="LunarLander: step through mgym_rollout, K steps per persistent launch (0: mgym_step); --steps / --warmup are rounded down to multiples of K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
@@ -114,7 +116,7 @@ def launch_mode(requested, family, launch_order="single_launch"):
 class Stepper:
     """One env family on this rank: device buffers, an action ring and a (graph-captured) step."""
 
-    def __init__(self, mg, torch, kind_name, n, device, seed, base, stream, reset_mode, launch):
+    def __init__(self, mg, torch, kind_name, n, device, seed, base, stream, reset_mode, launch, roll_k=0):
         kinds = {"cartpole": (mg.CARTPOLE, 2), "mountain_car": (mg.MOUNTAINCAR, 3),
                  "mountain_car_cont": (mg.MOUNTAINCAR_CONT, 0), "lunar_lander": (mg.LUNARLANDER, 4)}
         kind, nact = kinds[kind_name]
@@ -139,6 +141,13 @@ class Stepper:
         self.tail_graphs = {}
         self.timed = None
         self.t = 0
+        self.roll_k = roll_k if kind_name == "lunar_lander" else 0
+        if self.roll_k:   # mgym_rollout: a [K][n] action table and [K][n] outputs, one persistent launch per K steps
+            self.launch = "rollout"
+            self.roll_actions = torch.randint(0, nact, (self.roll_k, n), generator=g, device=f"cuda:{device}", dtype=torch.int32)
+            self.roll_out = (torch.empty((self.roll_k, n), device=f"cuda:{device}", dtype=torch.float32),
+                             torch.zeros((self.roll_k, n), device=f"cuda:{device}", dtype=torch.uint8), torch.zeros((self.roll_k, n), device=f"cuda:{device}", dtype=torch.uint8))
+            stream.wait_stream(torch.cuda.current_stream(device))
 
     def one(self, k):
         a = self.actions[k % RING]
@@ -169,6 +178,10 @@ class Stepper:
 
     def run(self, steps):
         """issue exactly `steps` steps on the stream"""
+        if self.roll_k:
+            for _ in range(steps // self.roll_k):
+                self.env.rollout_device(self.roll_actions, self.roll_k, None, *self.roll_out)
+            return
         if self.launch != "graph":
             for k in range(steps):
                 self.one(self.t + k)
@@ -229,7 +242,7 @@ def pmc_record(key):
     return None
 
 
-def lunar_roofline(n, step_s):
+def lunar_roofline(n, step_s, variant=""):
     """LunarLander is bound by f32 VALU issue / dependent chains (180 Gauss-Seidel sweeps per step), not by HBM:
     achieved = counted f32 FMA (x2) + MUL + ADD lane-operations per step (SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 x mean active
     lanes per VALU instruction, summed over the step's kernels; profiles/pmc_traffic.json) / this run's step time,
@@ -238,7 +251,9 @@ def lunar_roofline(n, step_s):
     out = {"bound": "valu", "peak": 157.3, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
            "kernel": "ll_step_kernel<32> (contact path, free-flight path, reset preparation as block roles of one launch) + ll_epilogue_kernel; from 425 984 envs: ll_contact_kernel<64> beside ll_free_kernel + ll_epilogue_kernel", "avg_step_us": step_s * 1e6,
            "hbm_for_reference": {"alg_bytes_per_step": alg, "GBps": alg / step_s / 1e9, "frac": alg / step_s / HBM_PEAK}}
-    rec = pmc_record(f"lunar_lander:{n}")
+    rec = pmc_record(f"lunar_lander{variant}:{n}")
+    if variant:
+        out["kernel"] = "ll_rollout_kernel<32> (one persistent launch per K steps: free-flight residents, contact / light-contact / reset batches through device queues)"
     if rec:
         out["achieved"] = rec["f32_flop_per_step_active_lanes"] / step_s / 1e12
         out["frac"] = out["achieved"] / 157.3
@@ -352,8 +367,11 @@ def main():
         n = plan[0][1]
     # one stream per family: the mixed batch's three step pipelines are independent and overlap on the device
     streams = [stream] + [torch.cuda.Stream(device=local_rank) for _ in plan[1:]]
-    steppers = [Stepper(mg, torch, name, cnt, local_rank, args.seed, gbase, st, args.reset, args.launch)
+    steppers = [Stepper(mg, torch, name, cnt, local_rank, args.seed, gbase, st, args.reset, args.launch, roll_k=args.ll_rollout)
                 for (name, cnt, gbase), st in zip(plan, streams)]
+    if args.ll_rollout and any(s_.roll_k for s_ in steppers):
+        args.steps = max(args.ll_rollout, args.steps // args.ll_rollout * args.ll_rollout)
+        args.warmup = args.warmup // args.ll_rollout * args.ll_rollout
     lead = steppers[0]
 
     def run(steps):
@@ -409,7 +427,8 @@ def main():
         "config": {"workload": {"cartpole": "CartPole-v1, 1048576 envs per GPU, f32 SoA (BASELINE configs[1])",
                                 "mixed": "Mixed CartPole+MountainCar+LunarLander, 1048576 envs per GPU (BASELINE configs[4] per-GPU load)"}
                    .get(args.workload, args.workload),
-                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": ", ".join(sorted({((f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if s_.launch == "graph" else "eager")
+                   "n_envs_per_gpu": sum(pop.values()), "n_envs_total": total_envs, "launch": ", ".join(sorted({(((f"graph (one hipGraph of {args.steps} step launches)" if one_graph else f"graph (hipGraph of {RING} steps, replayed)") if s_.launch == "graph" else "eager")
+                                                if s_.launch != "rollout" else f"mgym_rollout, {s_.roll_k} steps per persistent launch")
                                                 + (f" [{s_.name}]" if len(steppers) > 1 else "") for s_ in steppers})),
                    "reset": "fused auto-reset in the step kernel" if args.reset == "fused" else "separate mgym_reset_done launch per step",
                    "parallelism": f"index-sharded x{world}, no data-path collective", "action_ring": RING,
@@ -446,7 +465,7 @@ def main():
             result["roofline"]["traffic_source"] = rec.get("source")
 
     if args.workload == "lunar_lander":
-        result["roofline"] = lunar_roofline(n, ev_ms * 1e-3 / args.steps)
+        result["roofline"] = lunar_roofline(n, ev_ms * 1e-3 / args.steps, "_rollout%d" % args.ll_rollout if args.ll_rollout else "")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and (args.workload in ALG_BYTES or args.workload == "lunar_lander"):
         result["cpu_baseline"] = cpu_baseline(args.workload, n, args.seed)
 

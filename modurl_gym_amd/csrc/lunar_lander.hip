@@ -24,124 +24,22 @@
 //    event that can have produced one — set_state, dispersion override, unstaged resets)
 // Larger populations (64-lane contact blocks, World records in registers) and MGYM_LL_SINGLE_LAUNCH=0: the multi-stream order of
 // round 2 — ll_contact_kernel on the caller's stream beside ll_free_kernel + a short second contact launch on a helper stream (fork /
-// join by events), then the same epilogue.  MGYM_LL_FUSED_TAIL=0 / MGYM_LL_OVERLAP=0 / MGYM_LL_TOI_ROUNDS / MGYM_LL_BUCKET select the older
-// orders (counter memsets + ll_classify_kernel per step, select / copy launches, sequential kernels, follow-up TOI launches): profiling.
-// MGYM_LL_STAGED_RESET=0 computes a reset when the episode ends instead of preparing it ahead.
+// join by events), then the same epilogue.  MGYM_LL_STAGED_RESET=0 computes a reset when the episode ends instead of preparing it ahead.
+// mgym_rollout (K >= 8): ONE persistent launch, ll_roll.h.
+// The product library carries these two orders and the knobs its tests use (mgym_get_info lists them).  The older orders and block sizes
+// that only the measurements of rounds 2-3 used — counter memsets + ll_classify_kernel per step, select / copy launches, sequential kernels,
+// follow-up time-of-impact launches, contact blocks of 8 / 16 / 40 / 48 lanes, other free-flight occupancies — are compiled with -DLL_DIAG
+// only (tools/ build their own binaries that way).
 #include <math.h>
 #include <stdio.h>
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.h"
-#include "ll_env.h"
-#include "ll_free.h"
+#include "ll_kernel_common.h"
+#include "ll_roll_types.h"
 
 namespace mgym {
-
-
-__device__ __forceinline__ void stage_tab(PolyTab& tab, const LLConst& k) {
-    for (int t = threadIdx.x; t < 2 * kMaxPoly; t += blockDim.x) {  // blocks may be narrower than the table
-        int p = t / kMaxPoly, q = t % kMaxPoly;
-        tab.v[p][q] = k.poly_v[p][q];
-        tab.n[p][q] = k.poly_n[p][q];
-    }
-    if (threadIdx.x < 2) tab.count[threadIdx.x] = k.poly_count[threadIdx.x];
-    __syncthreads();
-}
-
-constexpr int kLLBlock = 64;  // one wave per block: heavy per-lane state, no intra-block cooperation
-// Touching contacts one island may hold.  9 is the geometric bound of this scene: a body's polygon spans < 2 m (lander
-// 1.13 m, leg diagonal 0.55 m) while terrain edges are 2 m wide, so it can touch at most two adjacent terrain edges plus
-// the base edge (0,0)-(W,0) when the terrain runs at y = 0: 3 bodies x 3.  (In LDS the contact kernel keeps the first 4 per lane, see kVcNearLds.)
-#ifndef LL_SOLVER_CAP
-#define LL_SOLVER_CAP 9
-#endif
-constexpr int kSolverCap = LL_SOLVER_CAP;
-constexpr int kVcNearLds = 2;  // of those, kept in LDS by the contact kernel (4 blocks per CU in either block size; the sweeps hold the first four in registers anyway); the rest in LLDev::vc_far
-// the staged KEY / SEQ / TOI words of the contact cache (ll_b2.h CtHot): one LDS column per lane of the block
-#define LL_HOT_DECL(BLKSZ) __shared__ uint32_t s_hot[3 * kSlots * (BLKSZ)]; const CtHot hot{(LL_LDS uint32_t*)s_hot + threadIdx.x, (uint32_t)(BLKSZ), 1u}
-// the per-lane working storage of the contact path (ll_world.h WorldTmp): one LDS record per lane of the block
-#define LL_TMP_DECL(BLKSZ) __shared__ WorldTmp s_tmp[(BLKSZ)]
-#define LL_TMP_PTR() ((LL_LDS WorldTmp*)s_tmp + threadIdx.x)
-constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kWorkReset (reset) or plain (general step)
-// Device-built lists (LLDev::work_list regions of n_pad words, lengths in LLDev::work_count):
-//   L_GENERAL    envs that need the contact path this step.  Filled from BOTH ends: envs without a touching contact from
-//                the front (count L_GENERAL), envs with one from the back (count L_GENERAL_T), so the waves of the
-//                worklist kernel hold environments of one kind (180 joint-only sweeps vs. sweeps with contact constraints).
-//   L_RESET      finished envs to reset (register-only fast path); L_RESET_SLOW: resets the fast path declined
-//   L_LATE       overlapped launch order only: envs the free-flight kernel had to decline (a contact would be created)
-//   L_RESET_DIRECT  staged resets: finished envs whose prepared episode does not fit (state imported, reset by the caller): reset the slow way
-//   L_PREP       staged resets: envs that have just been reset and whose NEXT reset is to be prepared (+ L_PREP_SLOW: declined by the fast path)
-//   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
-constexpr int kToiRounds = 4;
-//   C_NEXT       (a counter only) the length of the NEXT step's L_GENERAL while ll_epilogue_kernel is filling it; C_TICKET: its block ticket
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_TICKET, C_TICKET2,
-       L_COUNT, L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed by rebuild_list() / at the start of every call of the unfused order)
-
-struct LLIo {
-    const uint32_t* act;
-    float* obs_out;
-    float* rew;
-    uint8_t* done_out;
-    uint8_t* trunc_out;
-};
-
-__device__ __forceinline__ void ll_write_obs(const LLDev& d, const LLIo& io, uint64_t i, const float state[8]) {
-    for (int q = 0; q < 8; ++q) {
-        d.obs[(uint64_t)q * d.n_pad + i] = state[q];
-        if (io.obs_out) io.obs_out[(uint64_t)q * d.n + i] = state[q];
-    }
-}
-
-// wave-aggregated append of env indices to the worklist (done-mask style ballot + one atomic per wave)
-__device__ __forceinline__ void ll_push(const LLDev& d, int which, bool want, uint32_t entry) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;  // lane 0 may be inactive in a 32-lane block's tail
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(d.work_count + which, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (want) d.work_list[(uint64_t)which * d.n_pad + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
-}
-
-// the same from the back of list `which_list` (length kept in count slot `which_count`)
-__device__ __forceinline__ void ll_push_back(const LLDev& d, int which_list, int which_count, bool want, uint32_t entry) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(d.work_count + which_count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (want) d.work_list[(uint64_t)which_list * d.n_pad + (d.n_pad - 1u - (base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))))] = entry;
-}
-
-// block-aggregated append for kernels whose every wave appends (ll_classify_kernel): ONE atomic per block and list — thousands
-// of per-wave atomics on one counter serialise at ~11 ns each.  All threads of the block must call it (it synchronises);
-// `s_cnt` is block-shared scratch for (blockDim.x / 64 + 1) words.
-__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt, int which_count = -1) {
-    if (which_count < 0) which_count = which;   // (the epilogue fills next step's L_GENERAL under the counter C_NEXT)
-    const unsigned long long mask = __ballot(want);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    __syncthreads();  // s_cnt may still be read by the previous call
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < nw; ++w) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-        s_cnt[nw] = tot ? atomicAdd(d.work_count + which_count, tot) : 0u;
-    }
-    __syncthreads();
-    if (want) d.work_list[(uint64_t)which * d.n_pad + s_cnt[nw] + s_cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
-}
-
-// done-mask reduction for mgym_episode_count: ballot + popcount per wave pass, one fire-and-forget atomic per wave at the end
-__device__ __forceinline__ void ll_flush_done(const LLDev& d, uint32_t finished) {
-    if ((threadIdx.x & 63) == 0 && finished)
-        atomicAdd(d.done_count + ((blockIdx.x + (threadIdx.x >> 6)) & (kDoneShards - 1)), (unsigned long long)finished);
-}
 
 // Overlapped launch order, stage 0.  Which envs need the contact path is known from the flag word alone (a world exists,
 // and a body sleeps or a contact is cached), so that list is built up front and the contact kernel runs BESIDE the
@@ -331,34 +229,6 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // with all its sub-steps (toi_budget < 0, the default).  With toi_budget >= 0 (MGYM_LL_TOI_ROUNDS, profiling only) SolveTOI
 // stops after that many sub-steps and the env goes, with its unfinished state in the C_MID columns, onto L_TOI0 for
 // ll_toi_kernel.
-#ifndef LL_CONTACT_NUM_VGPR   // register budget of the contact kernel (arch VGPRs; the unified file holds twice that incl. AGPRs)
-#define LL_CONTACT_ATTR
-#else
-#define LL_CONTACT_ATTR __attribute__((amdgpu_num_vgpr(LL_CONTACT_NUM_VGPR)))
-#endif
-// threads per block of the contact kernel: a block is ONE wave.  With the World records in LDS (BLK <= 32) BLK of its lanes
-// carry an environment each; the other lanes of the wave exist only to take their share of the time-of-impact evaluations.
-constexpr int ll_contact_threads(int blk) { return blk <= 32 ? 64 : blk; }
-
-// The LDS of a block that runs the contact path:
-// velocity constraints per lane kept in LDS; the others go to the global workspace (CSolverMem)
-// Blocks of up to 32 lanes also keep the World record (bodies, joints, terrain heights, broad-phase boxes, the contact
-// being updated, collide_edge_polygon's polygon buffer, the slot lists: 720 B per lane, all indexed at run time) in LDS
-// instead of scratch: ~100 cycles per dependent access instead of >= 500 (1.45 -> 1.29 ms per step at 262 144 envs,
-// scratch 2096 -> 1280 B/lane).  LDS of a 32-lane block: 2 x 32 x 124 B constraints + 4.6 KB staged contact words +
-// 23 KB World + table = 38.2 KB (four blocks per CU); the sweeps hold the first four constraints in registers anyway.
-template <int BLK>
-struct ContactLds {
-    static constexpr bool kWorldLds = BLK <= 32;
-    World world[kWorldLds ? BLK : 1];
-    WorldTmp tmp[BLK];
-    PolyTab tab;
-    VConstraint vc[kVcNearLds * BLK];
-    uint32_t hot[(BLK > 32 ? 2 : 3) * kSlots * BLK];
-    uint16_t task[kWorldLds ? BLK * kSlots : 1];   // time-of-impact evaluations of the wave's current pass: (owner lane << 4) | contact slot
-    uint32_t late[64 * 4];                         // single-launch step: envs this wave's free-flight pass hands to its own contact path
-};
-
 // where a wave of the contact path takes its environments from: entry q of a list that is filled from both ends
 // (c0 entries from the front — rounded up to c0_up slots —, c1 from the back, `back` = index of the last slot)
 struct ContactList { const uint32_t* list; uint64_t back, c0, c0_up, c1; bool spread; };
@@ -504,12 +374,6 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
     }
 }
 
-__device__ __forceinline__ void ll_report(const LLDev& d, bool not_reset, uint32_t overflow, uint32_t finished) {
-    ll_flush_done(d, finished);
-    if (__any(not_reset) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_NOT_RESET);
-    if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
-    if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
-}
 
 // The contact path as a launch of its own (`which` = L_GENERAL, or L_LATE for the second launch of the overlapped order)
 template <int BLK>
@@ -539,6 +403,7 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     ll_report(d, not_reset, overflow, finished);
 }
 
+#ifdef LL_DIAG
 // Stage 3 of mgym_step, rounds r = 0 .. kToiRounds-1 over ever shorter lists: continue b2World::SolveTOI of the envs on
 // L_TOI0 + r by `budget` sub-steps (advance the body to its earliest impact, solve the TOI island, re-evaluate that body's
 // times of impact); finished envs get the tail of the step (observation, reward, termination), the others move on to
@@ -590,6 +455,8 @@ ll_toi_kernel(LLDev d, LLIo io, int round, int budget) {
     if (__any(overflow & 1u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_CONTACT_OVERFLOW);
     if (__any(overflow & 2u) && (threadIdx.x & 63) == 0) atomicOr(d.err, DEV_ERR_SOLVER_OVERFLOW);
 }
+
+#endif   // LL_DIAG
 
 // Whole general step in ONE launch (no time-of-impact rounds): the declined resets of L_RESET_SLOW (list != nullptr),
 // Testable::reset_deterministic, and the MGYM_LL_GENERAL_ONLY debugging aid.  list == nullptr: every env with
@@ -815,9 +682,10 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
     ll_report(d, not_reset, overflow, finished);
 }
 
-}  // namespace mgym
-#include "ll_roll.h"   // mgym_rollout: K steps in one persistent launch, environments advancing independently
-namespace mgym {
+// mgym_rollout: K steps in one persistent launch, environments advancing independently — ll_roll.h, compiled in ll_roll.hip
+int ll_rollout_blocks_per_cu(int* per_cu);
+void ll_rollout_ring_init(hipStream_t s, const RollQ& q);
+void ll_rollout_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q, uint32_t n);
 
 // Staged resets.  The state an env has after reset() — scene, implicit step(0), observation — is a pure function of
 // (seed, env id, episode counter), so it does not have to be computed when the episode ends, on the critical path of
@@ -825,6 +693,7 @@ namespace mgym {
 // reset kernels on a third stream while later steps run, and the auto-reset of a finished env is a copy.
 // The prepared state carries its episode counter: it fits iff shadow episode == live episode + 1; whatever changed the
 // live counter in between (mgym_reset, mgym_set_state) just sends the env down the direct path (L_RESET_DIRECT) once.
+#ifdef LL_DIAG   // (the unfused order's two launches; the fused order does both inside ll_epilogue_kernel)
 // (1) which finished envs have a fitting prepared state: those go onto L_PREP (their reset is the copy below, and their
 //     NEXT reset is prepared afterwards), the others onto L_RESET_DIRECT.  One thread per list entry, one atomic per block and list.
 __global__ void __launch_bounds__(256)
@@ -863,6 +732,8 @@ ll_apply_copy_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* 
         }
     }
 }
+
+#endif   // LL_DIAG
 
 // The END of a step in the fused order, one launch instead of counter memsets + classify (next step) + select + copy:
 //  (1) staged resets: every finished env (L_RESET) whose prepared next episode fits gets it copied in (and goes onto L_PREP: its
@@ -1006,6 +877,12 @@ __global__ void __launch_bounds__(kLLBlock) ll_import_kernel(LLDev d, const uint
     ll_store(d, i, w, e);
 }
 
+// tuning values of the persistent rollout launch: fixed in the product, read from the environment in -DLL_DIAG builds (tools/ll_roll_sweep.sh)
+#ifdef LL_DIAG
+#define LL_TUNE(name, dflt) (getenv(name) ? (uint32_t)atoi(getenv(name)) : (dflt))
+#else
+#define LL_TUNE(name, dflt) (dflt)
+#endif
 struct LunarLanderEnv final : Env {
     void* base = nullptr;
     void* obs_base = nullptr;
@@ -1030,11 +907,17 @@ struct LunarLanderEnv final : Env {
     bool prep_pending = false;          // work was put on aux2 that `stream` has not waited for yet
     int staged = getenv("MGYM_LL_STAGED_RESET") ? atoi(getenv("MGYM_LL_STAGED_RESET")) : 1;  // 1 (default): auto-resets are prepared ahead (see ll_apply_select_kernel)
     uint8_t* env_class = nullptr;       // [n] class of each env for this step (ll_classify_kernel): 0 free flight, 1 contact path
+#ifdef LL_DIAG
     int overlap = getenv("MGYM_LL_OVERLAP") ? atoi(getenv("MGYM_LL_OVERLAP")) : -1;  // 1 (default): contact kernel beside the free-flight kernel (see step()); 0: one after the other
+#else
+    int overlap = 1;
+#endif
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 0;   // lanes per block of the contact kernel; 0: by population (init)
+#ifdef LL_DIAG
     int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
+#endif
     // Launch structure of the contact path.  Measured on MI355X (profiles/r02_lunarlander/tune_launch_structure.txt), 262 144
     // envs, ms per step: whole world.step in the contact kernel, envs in index order 1.96 (default) | the same with
     // touching / non-touching envs bucketed into separate waves 2.12 | time-of-impact sub-steps in 1 / 4 follow-up
@@ -1042,14 +925,21 @@ struct LunarLanderEnv final : Env {
     // wave's dependent chain (island solve + up to 5 sub-steps of ~0.16 ms each), not a throughput limit: concentrating
     // heavy lanes (bucketing) lengthens that wave, and follow-up launches serialise the same chain behind launch
     // boundaries and a state round trip.  The alternatives stay selectable for profiling:
+#ifdef LL_DIAG
     int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : 0;       // 1: touching / non-touching envs at opposite ends of the worklist
     int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int fused_tail = getenv("MGYM_LL_FUSED_TAIL") ? atoi(getenv("MGYM_LL_FUSED_TAIL")) : 1;  // 1 (default): the fused order of step() (ll_epilogue_kernel); needs the overlapped order and none of the profiling knobs
+#else
+    static constexpr int bucket = 0, toi_rounds = 0;
+    int fused_tail = 1;   // (0 only with MGYM_LL_GENERAL_ONLY, the debugging aid that sends every env through ll_general_kernel)
+#endif
     int single_launch = getenv("MGYM_LL_SINGLE_LAUNCH") ? atoi(getenv("MGYM_LL_SINGLE_LAUNCH")) : 1;  // 1 (default): contact path, free-flight path and reset preparation in ONE launch (ll_step_kernel); needs the fused order and 32-lane contact blocks
-    int contact_blocks = getenv("MGYM_LL_CONTACT_BLOCKS") ? atoi(getenv("MGYM_LL_CONTACT_BLOCKS")) : -1;  // single-launch step: blocks the contact list is dealt out over (-1: by population, 0: always 32 lanes per block)
+    int contact_blocks = getenv("MGYM_LL_CONTACT_BLOCKS") ? atoi(getenv("MGYM_LL_CONTACT_BLOCKS")) : -1;  // single-launch step: blocks the contact list is dealt out over (default 900: as many as run at once beside the free-flight role; 0: always 32 lanes per block)
     int resume = getenv("MGYM_LL_RESUME") ? atoi(getenv("MGYM_LL_RESUME")) : 1;  // 1 (default): envs the free-flight kernel stops at a new contact are resumed after their island solve (0: redone from the old state)
+#ifdef LL_DIAG
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
+#endif
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
     // mgym_rollout as ONE persistent launch (ll_roll.h); MGYM_LL_ROLLOUT=0: K x step()
     int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : 1;
@@ -1096,6 +986,9 @@ struct LunarLanderEnv final : Env {
         // (round 3, single-launch step with 32-lane blocks against the multi-stream order with 64-lane blocks: 393 216 envs 1.54 / 1.57 ms,
         // 524 288: 2.04 / 1.68, 1 Mi: 3.81 / 2.86, 2 Mi: 7.38 / 6.11 — profiles/r03_lunarlander/population_block_matrix.txt)
         if (gen_block == 0) gen_block = n >= 425984 ? 64 : 32;
+#ifndef LL_DIAG
+        if (gen_block != 32 && gen_block != 64) { set_last_error("MGYM_LL_GENERAL_BLOCK: 32 or 64 (other contact-block sizes exist in -DLL_DIAG builds only)"); return MGYM_ERR_BAD_CONFIG; }
+#endif
         if (overlap < 0) overlap = 1;
         obs_dim = 8;
         state_cols = 27;
@@ -1182,35 +1075,35 @@ struct LunarLanderEnv final : Env {
             rq.ring = static_cast<unsigned long long*>(roll_ring);
             rq.ctl = static_cast<uint32_t*>(roll_ctl);
             rq.stat = reinterpret_cast<unsigned long long*>(rq.ctl + RC_WORDS * 32);
-            rq.contact_min = getenv("MGYM_LL_ROLL_CONTACT_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_CONTACT_MIN")) : 32u;
-            rq.heavy_min = getenv("MGYM_LL_ROLL_HEAVY_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_MIN")) : 16u;
-            rq.heavy_max = getenv("MGYM_LL_ROLL_HEAVY_MAX") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_MAX")) : 32u;
+            rq.contact_min = LL_TUNE("MGYM_LL_ROLL_CONTACT_MIN", 32u);
+            rq.heavy_min = LL_TUNE("MGYM_LL_ROLL_HEAVY_MIN", 16u);
+            rq.heavy_max = LL_TUNE("MGYM_LL_ROLL_HEAVY_MAX", 32u);
             if (rq.heavy_max > 32u) rq.heavy_max = 32u;
             if (rq.heavy_max < 1u) rq.heavy_max = 1u;
-            rq.tail_live = getenv("MGYM_LL_ROLL_TAIL_LIVE") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_TAIL_LIVE")) : 32768u;
-            rq.tail_lanes = getenv("MGYM_LL_ROLL_TAIL_LANES") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_TAIL_LANES")) : 4u;
+            rq.tail_live = LL_TUNE("MGYM_LL_ROLL_TAIL_LIVE", 32768u);
+            rq.tail_lanes = LL_TUNE("MGYM_LL_ROLL_TAIL_LANES", 4u);
             if (rq.tail_lanes > 32u) rq.tail_lanes = 32u;
             if (rq.tail_lanes < 1u) rq.tail_lanes = 1u;
-            rq.keep_min = getenv("MGYM_LL_ROLL_KEEP_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_KEEP_MIN")) : 24u;
-            rq.keep = getenv("MGYM_LL_ROLL_KEEP") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_KEEP")) : 1u;
-            rq.fair = getenv("MGYM_LL_ROLL_FAIR") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_FAIR")) : 0u;
-            rq.heavy_narrow = getenv("MGYM_LL_ROLL_HEAVY_NARROW") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_HEAVY_NARROW")) : 12u;
+            rq.keep_min = LL_TUNE("MGYM_LL_ROLL_KEEP_MIN", 24u);
+            rq.keep = LL_TUNE("MGYM_LL_ROLL_KEEP", 1u);
+            rq.fair = LL_TUNE("MGYM_LL_ROLL_FAIR", 0u);
+            rq.heavy_narrow = LL_TUNE("MGYM_LL_ROLL_HEAVY_NARROW", 12u);
             if (rq.heavy_narrow > rq.heavy_max) rq.heavy_narrow = rq.heavy_max;
             if (rq.heavy_narrow < 1u) rq.heavy_narrow = 1u;
-            rq.reset_min = getenv("MGYM_LL_ROLL_RESET_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_RESET_MIN")) : 16u;
-            rq.free_min = getenv("MGYM_LL_ROLL_FREE_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_FREE_MIN")) : 32u;
-            rq.residency = getenv("MGYM_LL_ROLL_RESIDENCY") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_RESIDENCY")) : 2u;
-            rq.refill_min = getenv("MGYM_LL_ROLL_REFILL_MIN") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_REFILL_MIN")) : 8u;
-            rq.debug = getenv("MGYM_LL_ROLL_DEBUG") ? (uint32_t)atoi(getenv("MGYM_LL_ROLL_DEBUG")) : 0u;
-            hipLaunchKernelGGL(ll_rollout_ring_init_kernel, dim3(256), dim3(256), 0, stream, rq);
+            rq.reset_min = LL_TUNE("MGYM_LL_ROLL_RESET_MIN", 16u);
+            rq.free_min = LL_TUNE("MGYM_LL_ROLL_FREE_MIN", 32u);
+            rq.residency = LL_TUNE("MGYM_LL_ROLL_RESIDENCY", 2u);
+            rq.refill_min = LL_TUNE("MGYM_LL_ROLL_REFILL_MIN", 8u);
+            rq.debug = LL_TUNE("MGYM_LL_ROLL_DEBUG", 0u);
+            ll_rollout_ring_init(stream, rq);
             int per_cu = 0, dev_id = 0;
             hipDeviceProp_t prop;
             MGYM_HIP(hipGetDevice(&dev_id));
             MGYM_HIP(hipGetDeviceProperties(&prop, dev_id));
-            MGYM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ll_rollout_kernel<32>, 64, 0));
+            if (ll_rollout_blocks_per_cu(&per_cu) != MGYM_OK) return MGYM_ERR_HIP;
             if (per_cu < 1) per_cu = 1;
             uint64_t g = (uint64_t)per_cu * (uint64_t)prop.multiProcessorCount;
-            if (getenv("MGYM_LL_ROLL_GRID")) g = (uint64_t)atoi(getenv("MGYM_LL_ROLL_GRID"));
+            if (LL_TUNE("MGYM_LL_ROLL_GRID", 0u)) g = (uint64_t)LL_TUNE("MGYM_LL_ROLL_GRID", 0u);
             const uint64_t need = (n + 31) / 32;   // more waves than 32-lane batches can never be busy
             if (g > need) g = need;
             if (g < 1) g = 1;
@@ -1237,8 +1130,7 @@ struct LunarLanderEnv final : Env {
                     done ? done + (size_t)k0 * n : nullptr, trunc ? trunc + (size_t)k0 * n : nullptr};
             RollQ q = rq; q.K = (uint32_t)kc;
             if (roll_trace) MGYM_HIP(hipMemsetAsync(roll_trace, 0, (size_t)roll_grid * kRollTraceLen * sizeof(unsigned long long), stream));
-            hipLaunchKernelGGL(ll_rollout_begin_kernel, dim3(1), dim3(64), 0, stream, q, (uint32_t)n);
-            hipLaunchKernelGGL(ll_rollout_kernel<32>, dim3(roll_grid), dim3(64), 0, stream, rd, io, q);
+            ll_rollout_launch(stream, roll_grid, rd, io, q, (uint32_t)n);
         }
         if (roll_trace) {
             std::vector<unsigned long long> h((size_t)roll_grid * kRollTraceLen);
@@ -1402,18 +1294,20 @@ struct LunarLanderEnv final : Env {
         return MGYM_OK;
     }
     void launch_free(hipStream_t s, const LLDev& d, const LLIo& io) {
-        switch (free_occ) {
-        case 1: hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, s, d, io); break;
-        case 3: hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, s, d, io); break;
-        default: hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, s, d, io); break;
-        }
+#ifdef LL_DIAG
+        if (free_occ == 1) { hipLaunchKernelGGL(ll_free_kernel<1>, grid(), dim3(kLLBlock), 0, s, d, io); return; }
+        if (free_occ == 3) { hipLaunchKernelGGL(ll_free_kernel<3>, grid(), dim3(kLLBlock), 0, s, d, io); return; }
+#endif
+        hipLaunchKernelGGL(ll_free_kernel<2>, grid(), dim3(kLLBlock), 0, s, d, io);   // two waves per SIMD (profiles/r02_lunarlander/tune_free_kernel_occupancy_overlapped.txt)
     }
     void launch_contact(hipStream_t s, int block, unsigned gb, const LLDev& d, const LLIo& io, int toi_budget, int which) {
         switch (block) {
+#ifdef LL_DIAG
         case 8: hipLaunchKernelGGL(ll_contact_kernel<8>, dim3(gb), dim3(ll_contact_threads(8)), 0, s, d, io, toi_budget, which); break;
         case 16: hipLaunchKernelGGL(ll_contact_kernel<16>, dim3(gb), dim3(ll_contact_threads(16)), 0, s, d, io, toi_budget, which); break;
         case 40: hipLaunchKernelGGL(ll_contact_kernel<40>, dim3(gb), dim3(ll_contact_threads(40)), 0, s, d, io, toi_budget, which); break;
         case 48: hipLaunchKernelGGL(ll_contact_kernel<48>, dim3(gb), dim3(ll_contact_threads(48)), 0, s, d, io, toi_budget, which); break;
+#endif
         case 64: hipLaunchKernelGGL(ll_contact_kernel<64>, dim3(gb), dim3(ll_contact_threads(64)), 0, s, d, io, toi_budget, which); break;
         default: hipLaunchKernelGGL(ll_contact_kernel<32>, dim3(gb), dim3(ll_contact_threads(32)), 0, s, d, io, toi_budget, which); break;
         }
@@ -1493,6 +1387,7 @@ struct LunarLanderEnv final : Env {
             MGYM_HIP(hipGetLastError());
             return MGYM_OK;
         }
+#ifdef LL_DIAG   // the unfused orders of rounds 1-2 (MGYM_LL_FUSED_TAIL=0, MGYM_LL_OVERLAP=0, MGYM_LL_TOI_ROUNDS, MGYM_LL_BUCKET): profiling builds only
         MGYM_HIP(hipMemsetAsync(dev.work_count, 0, L_COUNT * sizeof(uint32_t), stream));
         const int first_budget = toi_rounds > 0 ? toi_first : -1;  // sub-steps the contact kernel takes itself before handing an env to ll_toi_kernel
         if (overlap) {
@@ -1543,6 +1438,10 @@ struct LunarLanderEnv final : Env {
         }
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
+#else
+        set_last_error("LunarLander step: no launch order selected");   // (unreachable: general_only returned above, the fused order is the only other one)
+        return MGYM_ERR_BAD_CONFIG;
+#endif
     }
     int observation(const float** obs, uint64_t* col_stride) override {
         *obs = dev.obs; *col_stride = n_pad;
@@ -1552,6 +1451,8 @@ struct LunarLanderEnv final : Env {
     int info(std::string& out) override {
         out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
                "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) +
+               "\nknobs=MGYM_LL_GENERAL_BLOCK(32|64) MGYM_LL_SINGLE_LAUNCH MGYM_LL_STAGED_RESET MGYM_LL_STAGED_IN_GRAPH MGYM_LL_CONTACT_BLOCKS MGYM_LL_VC_NEAR MGYM_LL_RESUME MGYM_LL_GENERAL_ONLY "
+               "MGYM_LL_AUX_PRIO MGYM_LL_ROLLOUT MGYM_LL_ROLLOUT_MIN_K MGYM_LL_ROLL_STATS MGYM_LL_ROLL_TRACE" +
                "\nrollout=" + (roll_enabled ? "persistent_launch" : "k_steps") + "\nrollout_min_k=" + std::to_string(roll_min_k) + "\nrollout_waves=" + std::to_string(roll_grid) + "\n";
         if (capturing()) { set_last_error("mgym_get_info: the stream is being captured (the call launches probe kernels and synchronises)"); return MGYM_ERR_BAD_ARG; }
         hipStream_t ss[3] = {stream, aux, aux2};

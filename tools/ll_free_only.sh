@@ -1,3 +1,4 @@
+#!/bin/bash
 for rep in 1 2; do
 for cfg in "-" "MGYM_LL_SINGLE_LAUNCH=0" "MGYM_LL_SINGLE_LAUNCH=0 MGYM_LL_FREE_OCC=1" "MGYM_LL_SINGLE_LAUNCH=0 MGYM_LL_FREE_OCC=3"; do
   [ "$cfg" = "-" ] && envs="" || envs="$cfg"

@@ -22,7 +22,12 @@ __device__ inline unsigned long long diag_hash(std::initializer_list<float> w) {
 #define LL_DIAG_SWEEP(kind, it, ok, ...) do { dok_ = dok_ && (ok); unsigned long long h_ = diag_hash({__VA_ARGS__}); if (dper_ == 0) { for (int p_ = 0; p_ < 4; ++p_) if (h_ == dh_[p_]) { dper_ = p_ + 1; dit_ = it; break; } } dh_[3] = dh_[2]; dh_[2] = dh_[1]; dh_[1] = dh_[0]; dh_[0] = h_; } while (0)
 #define LL_DIAG_SWEEP_END(kind) do { if (dok_) atomicAdd(&g_cyc[kind][dper_][dit_ / 10], 1ull); } while (0)
 #endif
+#define LL_DIAG 1   // the measurement-only launch orders and block sizes (lunar_lander.hip)
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
+// (the persistent rollout launch lives in ll_roll.hip; these stand-alone measurement binaries never call it)
+namespace mgym { int ll_rollout_blocks_per_cu(int* per_cu) { *per_cu = 1; return 0; } void ll_rollout_ring_init(hipStream_t, const RollQ&) {}
+void ll_rollout_launch(hipStream_t, unsigned, const LLDev&, const LLIo&, const RollQ&, uint32_t) {} }
+
 #include <stdio.h>
 #include <vector>
 #include <algorithm>

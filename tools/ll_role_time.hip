@@ -3,7 +3,12 @@
 // NOT product code: a step with a role cut out is wrong physics; every variant restores the same saved state before its timed step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#define LL_DIAG 1   // the measurement-only launch orders and block sizes (lunar_lander.hip)
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
+// (the persistent rollout launch lives in ll_roll.hip; these stand-alone measurement binaries never call it)
+namespace mgym { int ll_rollout_blocks_per_cu(int* per_cu) { *per_cu = 1; return 0; } void ll_rollout_ring_init(hipStream_t, const RollQ&) {}
+void ll_rollout_launch(hipStream_t, unsigned, const LLDev&, const LLIo&, const RollQ&, uint32_t) {} }
+
 #include <stdio.h>
 #include <vector>
 namespace mgym {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON the GPU box: how long do the roles of the single-launch step kernel take apart?  Builds three diagnostic libraries
+# Runs ON the GPU box: how long do the roles of the single-launch step kernel take apart?  Builds four diagnostic binaries
 # (LL_ROLE_MASK: 1 contact only, 2 free flight only, 7 all) next to the product and times ONE step from the same saved state for
 # each (tools/_ll_role_time).  usage: tools/ll_role_time.sh [envs]
 set -e

@@ -4,6 +4,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 L=$REPO/modurl_gym_amd
 cp $L/libmgym.so /tmp/libmgym_cur.so
+trap 'cp /tmp/libmgym_cur.so $L/libmgym.so' EXIT   # the product library comes back whatever happens (an interrupted run must not leave a variant build in its place)
 cd /tmp && export TMPDIR=/tmp
 for s in $1; do
   [ "$s" = "cur" ] && cp /tmp/libmgym_cur.so $L/libmgym.so || cp $L/libmgym_$s.so $L/libmgym.so

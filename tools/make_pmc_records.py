@@ -28,7 +28,7 @@ def main():
     out = json.load(open(path)) if os.path.exists(path) else {}   # records of the other workloads stay
     for kv in sys.argv[2:]:
         key, tag = kv.split("=")
-        fam = key.split(":")[0].replace("_cont", "")
+        fam = key.split(":")[0].replace("_cont", "").split("_rollout")[0]
         summ = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}", "summary.json")))["kernels"]
         files = SRC[fam]
         rec = {"src_files": files, "src_sha16": sha16(files),
@@ -44,6 +44,9 @@ def main():
             lanes64 = active = hbm = 0.0
             per = {}
             steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_free_kernel" in k or "ll_step_kernel" in k] + [1])  # one step launch (or one free-flight launch) per step
+            if "_rollout" in key:   # one persistent launch per K steps: per-step figures = per-launch figures / K
+                kroll = int(key.split(":")[0].split("_rollout")[1])
+                steps = max([v.get("calls", 0) for k, v in summ.items() if "ll_rollout_kernel" in k] + [1]) * kroll
             for k, v in summ.items():
                 if "mgym::ll_" not in k or "pmc" not in v or "f32_flop_per_launch_lanes64" not in v["derived"] or v.get("calls", 0) < 10:
                     continue   # (one-shot kernels — the initial reset of the whole population — are not part of a step)
