@@ -49,10 +49,11 @@ struct RollCounters { int avail[RQ_COUNT]; uint32_t live; int headt[RQ_COUNT]; }
 LLD RollCounters rq_counters(const RollQ& q) {
     const int lane = threadIdx.x & 63;
     uint32_t v = 0u;
-    if (lane < 9) v = RQ_LOAD(rq_ctl(q, lane));
+    if (lane < RC_HEADT + RQ_COUNT) v = RQ_LOAD(rq_ctl(q, lane));
     RollCounters r;
     r.headt[0] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 0); r.headt[1] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 1);
     r.headt[2] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 2); r.headt[3] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 3);
+    r.headt[4] = __builtin_amdgcn_readlane((int)v, RC_HEADT + 4); r.avail[4] = __builtin_amdgcn_readlane((int)v, 4);
     r.avail[0] = __builtin_amdgcn_readlane((int)v, 0); r.avail[1] = __builtin_amdgcn_readlane((int)v, 1); r.avail[2] = __builtin_amdgcn_readlane((int)v, 2);
     r.avail[3] = __builtin_amdgcn_readlane((int)v, 3);
     r.live = (uint32_t)__builtin_amdgcn_readlane((int)v, RC_LIVE);
@@ -249,7 +250,7 @@ LLD void roll_write_scalars(const LLDev& d, const LLIo& io, uint32_t t, uint32_t
 //   RESET  finished and auto-reset is on (also when t1 == K: the reset belongs to step t)
 //   retire t1 == K
 //   FREE / CONTACT by the flag word, as ll_epilogue_kernel classes the next step's population
-enum { ROLL_NONE = 0, ROLL_TO_FREE, ROLL_TO_CONTACT, ROLL_TO_RESET, ROLL_TO_LIGHT, ROLL_RETIRE };
+enum { ROLL_NONE = 0, ROLL_TO_FREE, ROLL_TO_CONTACT, ROLL_TO_RESET, ROLL_TO_LIGHT, ROLL_TO_TOI, ROLL_RETIRE };
 LLD int roll_route(const LLDev& d, const RollQ& q, uint32_t flags, uint32_t done, uint32_t t1) {
     if (done && d.auto_reset) return ROLL_TO_RESET;
     if (t1 >= q.K) return ROLL_RETIRE;
@@ -261,6 +262,7 @@ LLD void roll_dispatch(const LLDev& d, const RollQ& q, int route, uint32_t i, ui
     rq_push(d, q, RQ_CONTACT, route == ROLL_TO_CONTACT, ent);
     rq_push(d, q, RQ_RESET, route == ROLL_TO_RESET, ent);
     rq_push(d, q, RQ_LIGHT, route == ROLL_TO_LIGHT, ent);
+    rq_push(d, q, RQ_TOI, route == ROLL_TO_TOI, ent);
     rq_retire(q, route == ROLL_RETIRE);
 }
 
@@ -272,7 +274,8 @@ LLD void roll_dispatch(const LLDev& d, const RollQ& q, int route, uint32_t i, ui
 // per step) out of every link of it.
 template <int BLK>
 __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& io, const RollQ& q, int m, ContactLds<BLK>& S, VConstraint* far_lane0, int far_stride,
-                                                   uint32_t& overflow, uint32_t& finished, int keep_which, int max_lanes, unsigned long long& n_batches, unsigned long long& n_lanes) {
+                                                   uint32_t& overflow, uint32_t& finished, int keep_which, int max_lanes, unsigned long long& n_batches, unsigned long long& n_lanes,
+                                                   bool resume_toi /* the entries stand at a sub-step (RQ_TOI) */, int toi_budget /* sub-steps this visit takes (< 0: all) */) {
     static_assert(BLK <= 32, "rollout: World records in LDS");
     constexpr int kThreads = ll_contact_threads(BLK);
     const PolyTab& tab = S.tab;
@@ -293,18 +296,19 @@ __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& i
         if (fresh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // their records were last written by other compute units, in this launch
         n_batches += 1ull; n_lanes += (unsigned long long)__popcll(__ballot(have));
         uint32_t action = 0u;
-        bool stepping = false, islanding = false;
+        bool stepping = false, islanding = false, unfinished = false;
         int n_refresh = 0;
         World& w = S.world[own];
         EnvRegs e;
         if (have) {
             w.t = (LL_LDS WorldTmp*)S.tmp + own;
-            ll_load(d, i, w, e, hot);
+            ll_load(d, i, w, e, hot, resume_toi);
         }
         if (q.debug & 16u) { if (have && e.step == 0xfffffff0u) atomicOr(d.err, DEV_ERR_INTERNAL); rq_retire(q, have); return; }   // (diagnosis: ... and the load)
         if (have) {
             action = io.act[(uint64_t)t * d.n + i];
-            if (w.resume) {   // the free-flight path has taken this step up to the end of the island solve (ll_free.h)
+            if (resume_toi) {   // world.step is past its island solve and its time-of-impact evaluations: on with SolveTOI
+            } else if (w.resume) {   // the free-flight path has taken this step up to the end of the island solve (ll_free.h)
                 ll_resume_after_island(w);
             } else {
                 float d0, d1, m_power, s_power;
@@ -336,8 +340,8 @@ __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& i
         }
         {   // b2World::SolveTOI, passes in lock step over the wave, time-of-impact evaluations dealt out over all 64 lanes
             ToiLoop L;
-            bool running = stepping && toi_begin(w, L, true);
-            int budget = -1;
+            bool running = stepping && toi_begin(w, L, !resume_toi);
+            int budget = toi_budget;
             while (__any(running)) {   // wave-uniform
                 const int n_need = running ? toi_list(w, L) : 0;
                 int incl = n_need;
@@ -351,12 +355,20 @@ __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& i
                     toi_evaluate(S.world[task >> 4], tab, (int)(task & 15u));
                 }
                 __syncthreads();
-                if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
+                if (running) {
+                    const int r = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget);
+                    running = r == TOI_AGAIN;
+                    unfinished = r == TOI_OUT_OF_BUDGET;
+                }
             }
         }
         int route = ROLL_NONE;
         bool is_done = false;
-        if (stepping) {
+        if (stepping && unfinished) {   // stands at a sub-step: stored mid-step, continued by a batch of its own kind
+            (void)ll_store(d, i, w, e, true);
+            route = ROLL_TO_TOI;
+            overflow |= w.overflow;
+        } else if (stepping) {
             float state[8], reward; uint32_t done;
             ll_step_finish(w, e, action, state, reward, done);
             const uint32_t flags = (q.debug & (32u | 256u)) ? (F_HAS_WORLD | 7u) : ll_store(d, i, w, e);
@@ -373,7 +385,7 @@ __device__ __forceinline__ void roll_contact_batch(const LLDev& d, const LLIo& i
             rq_drain();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             rq_drain();
-            roll_dispatch(d, q, route, i, t + 1u);
+            roll_dispatch(d, q, route, i, route == ROLL_TO_TOI ? t : t + 1u);
         }
         if (keep_which < 0) return;
         have = stay;
@@ -471,6 +483,7 @@ __device__ __forceinline__ void roll_reset_batch(const LLDev& d, const LLIo& io,
 // light queue; the residents have been flushed; the caller runs the batch — outside this function, so that the lanes' registers are dead by then)
 struct RollPending { int route; uint32_t ent; };   // an environment that has left its lane; its record is on its way to memory (written through)
 // issue: ONE atomic instruction reserves the ring positions of all three queues and takes the retiring environments off the live count
+// (environments leave free-flight mode for the free-flight, touching, reset and light queues or retire: queue numbers 0..3 and lane 4 for the live count)
 LLD uint32_t roll_dispatch_issue(const RollQ& q, const RollPending& p, unsigned long long (&mask)[5]) {
     const int lane = threadIdx.x & 63;
     mask[0] = __ballot(p.route == ROLL_TO_FREE); mask[1] = __ballot(p.route == ROLL_TO_CONTACT); mask[2] = __ballot(p.route == ROLL_TO_RESET);
@@ -486,7 +499,7 @@ LLD uint32_t roll_dispatch_issue(const RollQ& q, const RollPending& p, unsigned 
 LLD void roll_dispatch_complete(const LLDev& d, const RollQ& q, RollPending& p, const unsigned long long (&mask)[5], uint32_t ret) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int which = 0; which < RQ_COUNT; ++which) {
+    for (int which = 0; which < 4; ++which) {
         if (mask[which] == 0ull) continue;   // wave-uniform
         const uint32_t base = __shfl(ret, which);
         if (p.route == ROLL_TO_FREE + which) {
@@ -502,11 +515,11 @@ LLD void roll_dispatch_complete(const LLDev& d, const RollQ& q, RollPending& p, 
     }
     {   // published: one instruction, up to four words
         const unsigned long long mine = lane == 0 ? mask[0] : lane == 1 ? mask[1] : lane == 2 ? mask[2] : mask[3];
-        if (lane < RQ_COUNT && mine != 0ull) atomicAdd(rq_ctl(q, RC_AVAIL + lane), (uint32_t)__popcll(mine));
+        if (lane < 4 && mine != 0ull) atomicAdd(rq_ctl(q, RC_AVAIL + lane), (uint32_t)__popcll(mine));
     }
     p.route = ROLL_NONE;
 }
-static_assert(ROLL_TO_CONTACT == ROLL_TO_FREE + RQ_CONTACT && ROLL_TO_RESET == ROLL_TO_FREE + RQ_RESET && ROLL_TO_LIGHT == ROLL_TO_FREE + RQ_LIGHT, "routes follow the queue numbers");
+static_assert(ROLL_TO_CONTACT == ROLL_TO_FREE + RQ_CONTACT && ROLL_TO_RESET == ROLL_TO_FREE + RQ_RESET && ROLL_TO_LIGHT == ROLL_TO_FREE + RQ_LIGHT && ROLL_TO_TOI == ROLL_TO_FREE + RQ_TOI, "routes follow the queue numbers");
 
 template <int BLK>
 __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, ContactLds<BLK>& S, uint32_t& finished, RollStat& st) {
@@ -517,6 +530,7 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
     L.have = false;
     RollPending P; P.route = ROLL_NONE; P.ent = 0u;
     int f_headt = 0, c_headt = 0, l_headt = 0;
+    int t_avail = 0;
     int f_avail = 0, c_avail = 0, l_avail = 0;   // what waited in the free-flight / contact / light-contact queues when last looked at (one step ago)
     uint32_t on_board = 0u;         // steps since the wave last took a full load
     // take the entries at ring positions [h, h + m) into the vacant lanes: slots -> records (the one exposed round trip of a refill)
@@ -572,7 +586,7 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
             }
             __syncthreads();
             st.v[RS_T_FREE_QUEUE] += (unsigned long long)(wall_clock64() - tq0);
-            f_avail = 0; c_avail = 0; l_avail = 0; on_board = 0u;
+            f_avail = 0; c_avail = 0; l_avail = 0; t_avail = 0; on_board = 0u;
             vac = __ballot(!L.have);
             if (vac == ~0ull) return 0;
         }
@@ -607,14 +621,14 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
         // ... and the semaphore of the contact queue, if a full block was seen waiting (one attempt per step)
         int cclaim_want = 0, cclaim_old = 0;
         // (only a queue that is not AHEAD of the free-flight queue: see RC_HEADT)
-        const int cclaim_which = (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
+        const int cclaim_which = t_avail >= (int)q.toi_min ? RQ_TOI : (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
                                : (l_avail >= (int)q.contact_min && (!q.fair || f_avail <= 0 || l_headt <= f_headt)) ? RQ_LIGHT : -1;
         if (cclaim_which >= 0 && !(q.debug & 4u)) {
             cclaim_want = cclaim_which == RQ_CONTACT ? (c_headt < f_headt ? (int)q.heavy_narrow : (int)q.heavy_max) : BLK;
             if (lane == 0) cclaim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + cclaim_which), (uint32_t)cclaim_want);
         }
         uint32_t seen = 0u;   // next look at the semaphores
-        if (lane < 9) seen = RQ_LOAD(rq_ctl(q, lane));
+        if (lane < RC_HEADT + RQ_COUNT) seen = RQ_LOAD(rq_ctl(q, lane));
         // (3) the 180 velocity sweeps
         const long long ts2 = wall_clock64();
         for (int it = 0; it < 180; ++it) ll_free_sweep(L.f, k, L.s);
@@ -698,7 +712,7 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
             }
         }
         on_board += 1u;
-        f_avail = __builtin_amdgcn_readlane((int)seen, RQ_FREE); c_avail = __builtin_amdgcn_readlane((int)seen, RQ_CONTACT); l_avail = __builtin_amdgcn_readlane((int)seen, RQ_LIGHT);
+        f_avail = __builtin_amdgcn_readlane((int)seen, RQ_FREE); c_avail = __builtin_amdgcn_readlane((int)seen, RQ_CONTACT); l_avail = __builtin_amdgcn_readlane((int)seen, RQ_LIGHT); t_avail = __builtin_amdgcn_readlane((int)seen, RQ_TOI);
         f_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_FREE); c_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_CONTACT); l_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_LIGHT);
         st.v[RS_T_FREE_QUEUE] += (unsigned long long)((wall_clock64() - ts4) + (ts3 - tq0));
         // (7) what the contact semaphore has granted: everyone leaves the registers, the batch goes to the caller
@@ -733,7 +747,7 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
                 if (lane < m) S.late[lane] = ent;
                 __syncthreads();
                 st.v[RS_N_SWITCHES] += 1ull;
-                return cclaim_which == RQ_LIGHT ? -m : m;
+                return cclaim_which == RQ_LIGHT ? -m : cclaim_which == RQ_TOI ? m + 1000 : m;
             }
         }
     }
@@ -796,8 +810,9 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
         // the queue that is furthest behind among those with a batch's worth of entries (ties: touching contact, light contact, reset, free flight);
         // with nothing like that, any entries at all by the same rule
         int which = -1, best_t = 0x7fffffff;
-        const int order[RQ_COUNT] = {RQ_CONTACT, RQ_LIGHT, RQ_RESET, RQ_FREE};
-        const int need[RQ_COUNT] = {(int)q.free_min, c.live < q.tail_live ? 1 : (int)q.heavy_min, c.live < q.tail_live ? 1 : (int)q.reset_min, c.live < q.tail_live ? 1 : (int)q.contact_min};   // by queue number
+        const int order[RQ_COUNT] = {RQ_TOI, RQ_CONTACT, RQ_LIGHT, RQ_RESET, RQ_FREE};
+        const int need[RQ_COUNT] = {(int)q.free_min, c.live < q.tail_live ? 1 : (int)q.heavy_min, c.live < q.tail_live ? 1 : (int)q.reset_min, c.live < q.tail_live ? 1 : (int)q.contact_min,
+                                    c.live < q.tail_live ? 1 : (int)q.toi_min};   // by queue number
 #pragma unroll
         for (int o = 0; o < RQ_COUNT; ++o) { const int w = order[o]; const int ht = q.fair ? c.headt[w] : o; if (c.avail[w] >= need[w] && ht < best_t) { which = w; best_t = ht; } }
         if (which < 0) {
@@ -815,11 +830,11 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
             st.v[RS_T_FREE] += (unsigned long long)(wall_clock64() - tf0);
             idle_since = -1;
             if (m == 0) { st.v[RS_N_MAIN] += 1ull; continue; }
-            which = m < 0 ? RQ_LIGHT : RQ_CONTACT;
-            m = m < 0 ? -m : m;
+            which = m < 0 ? RQ_LIGHT : m > 1000 ? RQ_TOI : RQ_CONTACT;
+            m = m < 0 ? -m : m > 1000 ? m - 1000 : m;
         } else if (which >= 0) {
             uint32_t ent;
-            m = rq_pop(d, q, which, which == RQ_CONTACT ? heavy_lanes : (tail && which == RQ_LIGHT) ? (int)q.tail_lanes : BLK, ent);
+            m = rq_pop(d, q, which, which == RQ_CONTACT ? heavy_lanes : (tail && (which == RQ_LIGHT || which == RQ_TOI)) ? (int)q.tail_lanes : BLK, ent);
             if (m == 0) { st.v[RS_N_MAIN] += 1ull; continue; }   // others were faster: look again
             __syncthreads();
             if (lane < m) S.late[lane] = ent;
@@ -827,14 +842,21 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
         }
         if (which >= 0) {
             const long long tb0 = wall_clock64();
-            trace(which == RQ_RESET ? RT_RESET : which == RQ_LIGHT ? RT_LIGHT : RT_CONTACT);
+            trace(which == RQ_RESET ? RT_RESET : which == RQ_LIGHT ? RT_LIGHT : which == RQ_TOI ? RT_TOI : RT_CONTACT);
             if (which == RQ_RESET) roll_reset_batch<BLK>(d, io, q, m, S);
-            else if (which == RQ_LIGHT) roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished, (q.keep & 2u) ? RQ_LIGHT : -1, tail ? (int)q.tail_lanes : BLK, st.v[RS_N_LIGHT_BATCHES], st.v[RS_N_LIGHT_LANES]);
-            else roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished, (which == RQ_CONTACT && (q.keep & 1u)) ? RQ_CONTACT : -1, heavy_lanes, st.v[RS_N_CONTACT_BATCHES], st.v[RS_N_CONTACT_LANES]);   // (diagnosis 2: free-flight entries come here too)
+            else {   // ONE call site for the contact path's three kinds of batch (the body is large)
+                const int keep = which == RQ_LIGHT ? ((q.keep & 2u) ? RQ_LIGHT : -1) : (which == RQ_CONTACT && (q.keep & 1u)) ? RQ_CONTACT : -1;
+                const int lanes_max = which == RQ_CONTACT ? heavy_lanes : tail ? (int)q.tail_lanes : BLK;
+                const int budget = which == RQ_TOI ? ((q.toi_split & 4u) ? 1 : -1) : (which == RQ_LIGHT ? (q.toi_split & 1u) : which == RQ_CONTACT ? (q.toi_split & 2u) : 0u) ? 0 : -1;
+                unsigned long long& nb = which == RQ_LIGHT ? st.v[RS_N_LIGHT_BATCHES] : which == RQ_TOI ? st.v[RS_N_TOI_BATCHES] : st.v[RS_N_CONTACT_BATCHES];
+                unsigned long long& nl = which == RQ_LIGHT ? st.v[RS_N_LIGHT_LANES] : which == RQ_TOI ? st.v[RS_N_TOI_LANES] : st.v[RS_N_CONTACT_LANES];
+                roll_contact_batch<BLK>(d, io, q, m, S, far_lane0, far_stride, overflow, finished, keep, lanes_max, nb, nl, which == RQ_TOI, budget);   // (diagnosis 2: free-flight entries come here too)
+            }
             __syncthreads();
             const unsigned long long tb = (unsigned long long)(wall_clock64() - tb0);
             if (which == RQ_RESET) { st.v[RS_T_RESET] += tb; st.v[RS_N_RESET_LANES] += (unsigned long long)m; }
             else if (which == RQ_LIGHT) st.v[RS_T_LIGHT] += tb;
+            else if (which == RQ_TOI) st.v[RS_T_TOI] += tb;
             else st.v[RS_T_CONTACT] += tb;
             idle_since = -1;
             continue;

@@ -1084,6 +1084,8 @@ struct LunarLanderEnv final : Env {
             rq.tail_lanes = LL_TUNE("MGYM_LL_ROLL_TAIL_LANES", 4u);
             if (rq.tail_lanes > 32u) rq.tail_lanes = 32u;
             if (rq.tail_lanes < 1u) rq.tail_lanes = 1u;
+            rq.toi_split = LL_TUNE("MGYM_LL_ROLL_TOI_SPLIT", 7u);
+            rq.toi_min = LL_TUNE("MGYM_LL_ROLL_TOI_MIN", 24u);
             rq.keep_min = LL_TUNE("MGYM_LL_ROLL_KEEP_MIN", 24u);
             rq.keep = LL_TUNE("MGYM_LL_ROLL_KEEP", 1u);
             rq.fair = LL_TUNE("MGYM_LL_ROLL_FAIR", 0u);
@@ -1145,10 +1147,11 @@ struct LunarLanderEnv final : Env {
             const double w = h[RS_N_WAVES] ? (double)h[RS_N_WAVES] : 1.0, us = 0.01;
             auto per = [&](int t, int nn) { return h[nn] ? h[t] * us / h[nn] : 0.0; };
             fprintf(stderr, "ll_rollout K=%d waves=%.0f: per wave us: total %.0f seed %.0f | touching-contact %.0f (%.1f batches of %.1f lanes, %.0f us each) | light-contact %.0f (%.1f batches of %.1f lanes, %.0f us each) | "
-                            "reset %.0f (%.1f lanes) | free %.0f (%.1f steps of %.1f lanes, %.1f us each: begin %.1f issue %.1f sweeps %.1f finish %.1f queue %.1f; %.1f refills %.1f switches %.1f rotations) | idle %.0f, %.1f looks without work\n",
+                            "sub-steps %.0f (%.1f batches of %.1f lanes, %.0f us each) | reset %.0f (%.1f lanes) | free %.0f (%.1f steps of %.1f lanes, %.1f us each: begin %.1f issue %.1f sweeps %.1f finish %.1f queue %.1f; %.1f refills %.1f switches %.1f rotations) | idle %.0f, %.1f looks without work\n",
                     K, w, h[RS_T_TOTAL] * us / w, h[RS_T_SEED] * us / w,
                     h[RS_T_CONTACT] * us / w, h[RS_N_CONTACT_BATCHES] / w, h[RS_N_CONTACT_BATCHES] ? (double)h[RS_N_CONTACT_LANES] / h[RS_N_CONTACT_BATCHES] : 0.0, per(RS_T_CONTACT, RS_N_CONTACT_BATCHES),
                     h[RS_T_LIGHT] * us / w, h[RS_N_LIGHT_BATCHES] / w, h[RS_N_LIGHT_BATCHES] ? (double)h[RS_N_LIGHT_LANES] / h[RS_N_LIGHT_BATCHES] : 0.0, per(RS_T_LIGHT, RS_N_LIGHT_BATCHES),
+                    h[RS_T_TOI] * us / w, h[RS_N_TOI_BATCHES] / w, h[RS_N_TOI_BATCHES] ? (double)h[RS_N_TOI_LANES] / h[RS_N_TOI_BATCHES] : 0.0, per(RS_T_TOI, RS_N_TOI_BATCHES),
                     h[RS_T_RESET] * us / w, h[RS_N_RESET_LANES] / w,
                     h[RS_T_FREE] * us / w, h[RS_N_FREE_STEPS] / w, h[RS_N_FREE_STEPS] ? (double)h[RS_N_FREE_LANE_STEPS] / h[RS_N_FREE_STEPS] : 0.0, per(RS_T_FREE, RS_N_FREE_STEPS),
                     per(RS_T_FREE_BEGIN, RS_N_FREE_STEPS), per(RS_T_FREE_ISSUE, RS_N_FREE_STEPS), per(RS_T_FREE_SWEEPS, RS_N_FREE_STEPS), per(RS_T_FREE_FINISH, RS_N_FREE_STEPS), per(RS_T_FREE_QUEUE, RS_N_FREE_STEPS),
