@@ -481,146 +481,193 @@ __device__ __forceinline__ void roll_reset_batch(const LLDev& d, const LLIo& io,
 // them — issued and awaited on the spot they cost 170 us per wave-step with 1 024 waves at the same words (measured), a step 280 us.
 // Returns 0 when no lane holds an environment any more, or m != 0: a contact batch of |m| entries has been taken and sits in S.late (m < 0: from the
 // light queue; the residents have been flushed; the caller runs the batch — outside this function, so that the lanes' registers are dead by then)
-struct RollPending { int route; uint32_t ent; };   // an environment that has left its lane; its record is on its way to memory (written through)
-// issue: ONE atomic instruction reserves the ring positions of all three queues and takes the retiring environments off the live count
-// (environments leave free-flight mode for the free-flight, touching, reset and light queues or retire: queue numbers 0..3 and lane 4 for the live count)
-LLD uint32_t roll_dispatch_issue(const RollQ& q, const RollPending& p, unsigned long long (&mask)[5]) {
+struct RollPending { int route; uint32_t ent; };   // an environment that has left its slot; its record is on its way to memory (written through)
+// A lane of a wave in free-flight mode can carry kRollPer environments side by side through the sweeps (two independent dependent chains in one
+// instruction stream).  Built for LL_ROLL_PER = 2 and measured (profiles/r04_lunarlander/rollout_two_per_lane.txt): the double sweep is 230 VALU
+// instructions, 137 of them packed (one environment: 124), and takes 85 us per 180 instead of 2 x 50 — but the parts around the sweeps (wind,
+// sincos in f64, fixture synchronisation: 18 + 21 us against 9 + 11) do not overlap, and a wave of 128 slots runs 86 % full (refills arrive 64 at a
+// time) instead of 98 %: 82 us per 64 environment-steps against 80.  One per lane is the default; the code below is written for any count.
+#ifndef LL_ROLL_PER
+#define LL_ROLL_PER 1
+#endif
+constexpr int kRollPer = LL_ROLL_PER;
+// issue: ONE atomic instruction hands out the ring positions of the queues a free-flight environment can leave for (free flight, touching, reset,
+// light: queue numbers 0..3) and takes the retiring environments off the live count (lane 4)
+LLD uint32_t roll_dispatch_issue(const RollQ& q, const RollPending (&p)[kRollPer], unsigned long long (&mask)[kRollPer][5]) {
     const int lane = threadIdx.x & 63;
-    mask[0] = __ballot(p.route == ROLL_TO_FREE); mask[1] = __ballot(p.route == ROLL_TO_CONTACT); mask[2] = __ballot(p.route == ROLL_TO_RESET);
-    mask[3] = __ballot(p.route == ROLL_TO_LIGHT); mask[4] = __ballot(p.route == ROLL_RETIRE);
-    uint32_t ret = 0u;
-    if (lane < 5) {
-        const uint32_t cnt = (uint32_t)__popcll(lane == 0 ? mask[0] : lane == 1 ? mask[1] : lane == 2 ? mask[2] : lane == 3 ? mask[3] : mask[4]);
-        if (cnt) ret = atomicAdd(lane < 4 ? rq_ctl(q, RC_TAIL + lane) : rq_ctl(q, RC_LIVE), lane < 4 ? cnt : 0u - cnt);
+    uint32_t cnt = 0u;
+#pragma unroll
+    for (int z = 0; z < kRollPer; ++z) {
+        mask[z][0] = __ballot(p[z].route == ROLL_TO_FREE); mask[z][1] = __ballot(p[z].route == ROLL_TO_CONTACT); mask[z][2] = __ballot(p[z].route == ROLL_TO_RESET);
+        mask[z][3] = __ballot(p[z].route == ROLL_TO_LIGHT); mask[z][4] = __ballot(p[z].route == ROLL_RETIRE);
+        cnt += (uint32_t)__popcll(lane == 0 ? mask[z][0] : lane == 1 ? mask[z][1] : lane == 2 ? mask[z][2] : lane == 3 ? mask[z][3] : mask[z][4]);
     }
+    uint32_t ret = 0u;
+    if (lane < 5 && cnt) ret = atomicAdd(lane < 4 ? rq_ctl(q, RC_TAIL + lane) : rq_ctl(q, RC_LIVE), lane < 4 ? cnt : 0u - cnt);
     return ret;
 }
 // complete: the entries go into the slots at their ring positions (the caller has waited for the records: rq_drain), then they count as published
-LLD void roll_dispatch_complete(const LLDev& d, const RollQ& q, RollPending& p, const unsigned long long (&mask)[5], uint32_t ret) {
+LLD void roll_dispatch_complete(const LLDev& d, const RollQ& q, RollPending (&p)[kRollPer], const unsigned long long (&mask)[kRollPer][5], uint32_t ret) {
     const int lane = threadIdx.x & 63;
+    uint32_t published = 0u;
 #pragma unroll
     for (int which = 0; which < 4; ++which) {
-        if (mask[which] == 0ull) continue;   // wave-uniform
-        const uint32_t base = __shfl(ret, which);
-        if (p.route == ROLL_TO_FREE + which) {
-            const uint32_t pos = base + (uint32_t)__popcll(mask[which] & ((1ull << lane) - 1ull));
-            unsigned long long* const s = rq_slot(q, which, pos);
-            if ((uint32_t)(RQ_LOAD(s) >> 32) != pos) {
-                const long long t0 = wall_clock64();
-                while ((uint32_t)(RQ_LOAD(s) >> 32) != pos && wall_clock64() - t0 < kRollTimeoutTicks && !rq_aborted(q)) __builtin_amdgcn_s_sleep(2);
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) any |= mask[z][which];
+        if (any == 0ull) continue;   // wave-uniform
+        uint32_t pos0 = __shfl(ret, which);
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) {
+            if (p[z].route == ROLL_TO_FREE + which) {
+                const uint32_t pos = pos0 + (uint32_t)__popcll(mask[z][which] & ((1ull << lane) - 1ull));
+                unsigned long long* const s = rq_slot(q, which, pos);
+                if ((uint32_t)(RQ_LOAD(s) >> 32) != pos) {
+                    const long long t0 = wall_clock64();
+                    while ((uint32_t)(RQ_LOAD(s) >> 32) != pos && wall_clock64() - t0 < kRollTimeoutTicks && !rq_aborted(q)) __builtin_amdgcn_s_sleep(2);
+                }
+                if ((uint32_t)(RQ_LOAD(s) >> 32) == pos) RQ_STORE(s, ((unsigned long long)(pos + 1u) << 32) | p[z].ent);
+                else rq_abort(d, q);
             }
-            if ((uint32_t)(RQ_LOAD(s) >> 32) == pos) RQ_STORE(s, ((unsigned long long)(pos + 1u) << 32) | p.ent);
-            else rq_abort(d, q);
+            pos0 += (uint32_t)__popcll(mask[z][which]);
+            if (lane == which) published += (uint32_t)__popcll(mask[z][which]);
         }
     }
-    {   // published: one instruction, up to four words
-        const unsigned long long mine = lane == 0 ? mask[0] : lane == 1 ? mask[1] : lane == 2 ? mask[2] : mask[3];
-        if (lane < 4 && mine != 0ull) atomicAdd(rq_ctl(q, RC_AVAIL + lane), (uint32_t)__popcll(mine));
-    }
-    p.route = ROLL_NONE;
+    if (lane < 4 && published) atomicAdd(rq_ctl(q, RC_AVAIL + lane), published);   // one instruction, up to four words
+#pragma unroll
+    for (int z = 0; z < kRollPer; ++z) p[z].route = ROLL_NONE;
 }
 static_assert(ROLL_TO_CONTACT == ROLL_TO_FREE + RQ_CONTACT && ROLL_TO_RESET == ROLL_TO_FREE + RQ_RESET && ROLL_TO_LIGHT == ROLL_TO_FREE + RQ_LIGHT && ROLL_TO_TOI == ROLL_TO_FREE + RQ_TOI, "routes follow the queue numbers");
 
+// Returns 0 when no slot holds an environment any more, or m != 0: a batch of the contact path has been taken and sits in S.late (m < 0: |m| entries
+// from the light queue, m > 1000: m - 1000 from the sub-step queue, else m from the touching queue; the residents have been flushed; the caller runs
+// the batch — outside this function, so that the slots' registers are dead by then)
 template <int BLK>
 __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, ContactLds<BLK>& S, uint32_t& finished, RollStat& st) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
     const PolyTab& tab = S.tab;
     const LLConst& k = LLK(d);
-    RollLane L = {};
-    L.have = false;
-    RollPending P; P.route = ROLL_NONE; P.ent = 0u;
+    RollLane L[kRollPer] = {};
+    RollPending P[kRollPer];
+#pragma unroll
+    for (int z = 0; z < kRollPer; ++z) { L[z].have = false; P[z].route = ROLL_NONE; P[z].ent = 0u; }
     int f_headt = 0, c_headt = 0, l_headt = 0;
     int t_avail = 0;
     int f_avail = 0, c_avail = 0, l_avail = 0;   // what waited in the free-flight / contact / light-contact queues when last looked at (one step ago)
     uint32_t on_board = 0u;         // steps since the wave last took a full load
-    // take the entries at ring positions [h, h + m) into the vacant lanes: slots -> records (the one exposed round trip of a refill)
-    auto fill = [&](uint32_t h, int m, unsigned long long vac) {
-        const uint32_t ent = rq_take(d, q, RQ_FREE, h, m);
-        __syncthreads();
-        if (lane < m) S.late[lane] = ent;
-        __syncthreads();
-        const int rank = __popcll(vac & ((1ull << lane) - 1ull));
-        const bool take = ((vac >> lane) & 1ull) && rank < m && S.late[rank < m ? rank : 0] != 0xffffffffu;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (take) {
-            const uint32_t e2 = S.late[rank];
-            L.i = roll_env_of(e2); L.t = e2 >> 24;
-            RollRec r;
-            roll_rec_load(rs, L.i, r);
-            roll_unpack(d, r, L.f, L.e);
-            L.seq_word = r.w[C_SEQ];
-            L.have = true; L.fresh = true;
-            L.act = io.act[(uint64_t)L.t * d.n + L.i];
+    auto board = [&](RollLane& X, uint32_t e2) {   // an entry comes on board: its record's two leading lines, the action of its next step
+        X.i = roll_env_of(e2); X.t = e2 >> 24;
+        RollRec r;
+        roll_rec_load(rs, X.i, r);
+        roll_unpack(d, r, X.f, X.e);
+        X.seq_word = r.w[C_SEQ];
+        X.have = true; X.fresh = true;
+        X.act = io.act[(uint64_t)X.t * d.n + X.i];
+    };
+    // take the entries at ring positions [h, h + m) into the vacant slots (slot order: all lanes' first, then all lanes' second): slots -> records
+    // (the one exposed round trip of a refill)
+    auto fill = [&](uint32_t h, int m, const unsigned long long (&vac)[kRollPer]) {
+        for (int c0 = 0; c0 < m; c0 += 64) {   // (a wave takes 64 entries out of their slots at a time)
+            const int mc = m - c0 < 64 ? m - c0 : 64;
+            const uint32_t ent = rq_take(d, q, RQ_FREE, h + (uint32_t)c0, mc);
+            __syncthreads();
+            if (lane < mc) S.late[lane] = ent;
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            int before = 0;
+#pragma unroll
+            for (int z = 0; z < kRollPer; ++z) {
+                const int rank = before + __popcll(vac[z] & below) - c0;
+                if (((vac[z] >> lane) & 1ull) && rank >= 0 && rank < mc && S.late[rank] != 0xffffffffu) board(L[z], S.late[rank]);
+                before += __popcll(vac[z]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    };
+    auto flush_pending = [&]() {   // on the spot (leaving the mode, switching to a batch): what is pending goes into its queues now
+        bool any = false;
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) any = any || P[z].route != ROLL_NONE;
+        if (__any(any)) {
+            unsigned long long pm[kRollPer][5];
+            const uint32_t ret = roll_dispatch_issue(q, P, pm);
+            rq_drain();
+            roll_dispatch_complete(d, q, P, pm, ret);
+        }
+    };
+    auto leave_for_queue = [&](RollLane& X, RollPending& Pz) {   // a resident goes back to the free-flight queue (record written through if it was stepped here)
+        if (X.have) {
+            if (!X.fresh) {
+                RollRec r;
+                roll_pack_store(r, X.f, X.e, X.f.flags, X.seq_word);
+                roll_rec_store(rs, X.i, r);
+            }
+            Pz.route = ROLL_TO_FREE; Pz.ent = (X.t << 24) | X.i;
+            X.have = false;
+        }
     };
     for (;;) {
-        unsigned long long vac = __ballot(!L.have);
-        if (vac == ~0ull) {   // nobody on board (entering the mode, or everyone has left): finish what is pending, then a refill on the spot
-            if (__any(P.route != ROLL_NONE)) {
-                unsigned long long pm[5];
-                const uint32_t ret = roll_dispatch_issue(q, P, pm);
-                rq_drain();
-                roll_dispatch_complete(d, q, P, pm, ret);
-            }
+        unsigned long long vac[kRollPer];
+        int n_vac = 0;
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) { vac[z] = __ballot(!L[z].have); n_vac += __popcll(vac[z]); }
+        if (n_vac == 64 * kRollPer) {   // nobody on board (entering the mode, or everyone has left): finish what is pending, then a refill on the spot
+            flush_pending();
             uint32_t ent;
             const long long tq0 = wall_clock64();
             const int m = rq_pop(d, q, RQ_FREE, 64, ent);
             st.v[RS_N_REFILLS] += 1ull;
             if (m == 0) return 0;
-            // (rq_pop has taken the entries out of their slots already: hand them over as `fill` does)
             __syncthreads();
-            if (lane < m) S.late[lane] = ent;
+            if (lane < m) S.late[lane] = ent;   // (rq_pop has taken the entries out of their slots already)
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (lane < m && S.late[lane] != 0xffffffffu) {
-                const uint32_t e2 = S.late[lane];
-                L.i = roll_env_of(e2); L.t = e2 >> 24;
-                RollRec r;
-                roll_rec_load(rs, L.i, r);
-                roll_unpack(d, r, L.f, L.e);
-                L.seq_word = r.w[C_SEQ];
-                L.have = true; L.fresh = true;
-                L.act = io.act[(uint64_t)L.t * d.n + L.i];
-            L.act = io.act[(uint64_t)L.t * d.n + L.i];
-            }
+            if (lane < m && S.late[lane] != 0xffffffffu) board(L[0], S.late[lane]);
             __syncthreads();
             st.v[RS_T_FREE_QUEUE] += (unsigned long long)(wall_clock64() - tq0);
             f_avail = 0; c_avail = 0; l_avail = 0; t_avail = 0; on_board = 0u;
-            vac = __ballot(!L.have);
-            if (vac == ~0ull) return 0;
+            n_vac = 0;
+#pragma unroll
+            for (int z = 0; z < kRollPer; ++z) { vac[z] = __ballot(!L[z].have); n_vac += __popcll(vac[z]); }
+            if (n_vac == 64 * kRollPer) return 0;
         }
-        st.v[RS_N_FREE_STEPS] += 1ull; st.v[RS_N_FREE_LANE_STEPS] += (unsigned long long)__popcll(~vac);
+        st.v[RS_N_FREE_STEPS] += 1ull; st.v[RS_N_FREE_LANE_STEPS] += (unsigned long long)(64 * kRollPer - n_vac);
         const long long ts0 = wall_clock64();
         // (1) one Gym::step of every resident environment: up to the sweeps
-        bool run = false, declined = false;
-        if (L.have) {
-            const uint32_t action = L.act;
-            float d0, d1;
-            ll_dispersion(d, L.i, L.e, d0, d1);
-            run = ll_free_begin<true>(d, L.i, L.f, L.e, action, d0, d1, L.s);
-            declined = !run;   // a pending proxy overlaps the ground (only right after a reset / state import): the contact path, from the record in HBM
+        bool run[kRollPer], declined[kRollPer];
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) {
+            run[z] = false; declined[z] = false;
+            if (L[z].have) {
+                float d0, d1;
+                ll_dispersion(d, L[z].i, L[z].e, d0, d1);
+                run[z] = ll_free_begin<true>(d, L[z].i, L[z].f, L[z].e, L[z].act, d0, d1, L[z].s);
+                declined[z] = !run[z];   // a pending proxy overlaps the ground (only right after a reset / state import): the contact path, from the record in HBM
+            }
         }
         // (2) queue traffic, issued now and used after the sweeps
         const long long ts1 = wall_clock64();
-        unsigned long long pm[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-        const bool pushing = __any(P.route != ROLL_NONE);
+        unsigned long long pm[kRollPer][5];
+        bool pend = false;
+#pragma unroll
+        for (int z = 0; z < kRollPer; ++z) pend = pend || P[z].route != ROLL_NONE;
+        const bool pushing = __any(pend);
         uint32_t push_ret = 0u;
         if (pushing) push_ret = roll_dispatch_issue(q, P, pm);
-        const int n_vac = __popcll(vac);
-        // ... the semaphore of the free-flight queue, for the vacant lanes, if entries were seen waiting a step ago
+        // ... the semaphore of the free-flight queue, for the vacant slots, if entries were seen waiting a step ago
         int claim_want = 0, claim_old = 0;
-        const bool rotate = f_avail >= 64 && on_board + 1u >= q.residency;   // after this step everyone on board makes room for 64 that wait
+        const bool rotate = f_avail >= 64 * kRollPer && on_board + 1u >= q.residency;   // after this step everyone on board makes room for a load that waits
         if (rotate) {
-            claim_want = 64;
+            claim_want = 64 * kRollPer;
             if (lane == 0) claim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + RQ_FREE), (uint32_t)claim_want);
         } else if (f_avail > 0 && n_vac >= (int)q.refill_min) {
             claim_want = f_avail < n_vac ? f_avail : n_vac;
             if (lane == 0) claim_old = (int)atomicSub(rq_ctl(q, RC_AVAIL + RQ_FREE), (uint32_t)claim_want);
         }
-        // ... and the semaphore of the contact queue, if a full block was seen waiting (one attempt per step)
+        // ... and the semaphore of a contact-path queue, if a batch's worth was seen waiting (one attempt per step)
         int cclaim_want = 0, cclaim_old = 0;
-        // (only a queue that is not AHEAD of the free-flight queue: see RC_HEADT)
+        // (only a queue that is not AHEAD of the free-flight queue when q.fair: see RC_HEADT)
         const int cclaim_which = t_avail >= (int)q.toi_min ? RQ_TOI : (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
                                : (l_avail >= (int)q.contact_min && (!q.fair || f_avail <= 0 || l_headt <= f_headt)) ? RQ_LIGHT : -1;
         if (cclaim_which >= 0 && !(q.debug & 4u)) {
@@ -629,65 +676,74 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
         }
         uint32_t seen = 0u;   // next look at the semaphores
         if (lane < RC_HEADT + RQ_COUNT) seen = RQ_LOAD(rq_ctl(q, lane));
-        // (3) the 180 velocity sweeps
+        // (3) the 180 velocity sweeps, the slots of a lane side by side
         const long long ts2 = wall_clock64();
-        for (int it = 0; it < 180; ++it) ll_free_sweep(L.f, k, L.s);
+        for (int it = 0; it < 180; ++it) {
+#pragma unroll
+            for (int z = 0; z < kRollPer; ++z) ll_free_sweep(L[z].f, k, L[z].s);
+        }
         // (4) the environments that left in the previous step go into the slots reserved for them
         const long long tq0 = wall_clock64();
         st.v[RS_T_FREE_BEGIN] += (unsigned long long)(ts1 - ts0); st.v[RS_T_FREE_ISSUE] += (unsigned long long)(ts2 - ts1); st.v[RS_T_FREE_SWEEPS] += (unsigned long long)(tq0 - ts2);
         if (pushing) { rq_drain(); roll_dispatch_complete(d, q, P, pm, push_ret); }
         const long long ts3 = wall_clock64();
-        // (5) the rest of the step; environments that leave their lane become pending
-        bool is_done = false;
-        if (run) {
-            float state[8], reward; uint32_t done, moved;
-            const int how = ll_free_finish<true>(d, L.i, L.f, L.e, tab, L.s, state, reward, done, moved);
-            if (how == FREE_DONE) {
-                const uint32_t flags = roll_flags_after_step(L.f, L.e);
-                const int route = roll_route(d, q, flags, done, L.t + 1u);
-                if (route == ROLL_TO_FREE) L.act = io.act[(uint64_t)(L.t + 1u) * d.n + L.i];   // stays on board: next step's action, ahead of this step's stores
-                roll_write_scalars(d, io, L.t, L.i, reward, done);
-                if (route != ROLL_TO_RESET) roll_write_obs(d, io, L.t, L.i, state, L.t + 1u == q.K);
-                is_done = done != 0u;
-                // the lane's registers as a store + load of the record would leave them
-                L.f.flags = flags;
+        // (5) the rest of the step; environments that leave their slot become pending
+        uint32_t n_done = 0u;
 #pragma unroll
-                for (int b = 0; b < 3; ++b) { L.f.b[b].force = mk(0.0f, 0.0f); L.f.b[b].torque = 0.0f; }
-                L.t += 1u; L.fresh = false;
-                if (route != ROLL_TO_FREE) {   // the environment leaves the registers: its record goes back, written through
+        for (int z = 0; z < kRollPer; ++z) {
+            RollLane& X = L[z];
+            bool is_done = false;
+            if (run[z]) {
+                float state[8], reward; uint32_t done, moved;
+                const int how = ll_free_finish<true>(d, X.i, X.f, X.e, tab, X.s, state, reward, done, moved);
+                if (how == FREE_DONE) {
+                    const uint32_t flags = roll_flags_after_step(X.f, X.e);
+                    const int route = roll_route(d, q, flags, done, X.t + 1u);
+                    if (route == ROLL_TO_FREE) X.act = io.act[(uint64_t)(X.t + 1u) * d.n + X.i];   // stays on board: next step's action, ahead of this step's stores
+                    roll_write_scalars(d, io, X.t, X.i, reward, done);
+                    if (route != ROLL_TO_RESET) roll_write_obs(d, io, X.t, X.i, state, X.t + 1u == q.K);
+                    is_done = done != 0u;
+                    // the slot's registers as a store + load of the record would leave them
+                    X.f.flags = flags;
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) { X.f.b[b].force = mk(0.0f, 0.0f); X.f.b[b].torque = 0.0f; }
+                    X.t += 1u; X.fresh = false;
+                    if (route != ROLL_TO_FREE) {   // the environment leaves the registers: its record goes back, written through
+                        RollRec r;
+                        roll_pack_store(r, X.f, X.e, flags, X.seq_word);
+                        roll_rec_store(rs, X.i, r);
+                        P[z].route = route; P[z].ent = (X.t << 24) | X.i;
+                        X.have = false;
+                    }
+                } else {   // FREE_RESUME: a contact is being created at the end of the step — ≙ ll_free_store_resume, then the contact path finishes step t
                     RollRec r;
-                    roll_pack_store(r, L.f, L.e, flags, L.seq_word);
-                    roll_rec_store(rs, L.i, r);
-                    P.route = route; P.ent = (L.t << 24) | L.i;
-                    L.have = false;
-                }
-            } else {   // FREE_RESUME: a contact is being created at the end of the step — ≙ ll_free_store_resume, then the contact path finishes step t
-                RollRec r;
-                uint32_t awake_bits;
-                roll_pack_common(r, L.f, awake_bits);
-                const uint32_t flags = (L.f.flags & (F_GAME_OVER | F_LEG0 | F_LEG1 | F_HAS_WORLD | F_DETERMINISTIC | F_STEPPED | F_PREV_SOME)) | awake_bits;
-                r.w[C_FLAGS] = flags | F_RESUME | ((moved & 7u) << 9);
-                r.w[C_PREV] = as_u32(L.e.prev_shaping);                          // (unchanged by the unfinished step; the record may be older than the registers)
-                r.w[C_WIND] = (uint32_t)L.e.wind_idx; r.w[C_TORQUE] = (uint32_t)L.e.torque_idx;
-                r.w[C_STEP] = L.e.step; r.w[C_EPISODE] = L.e.episode; r.w[C_SEQ] = L.seq_word;
-                roll_rec_store(rs, L.i, r);
-                const uint32_t off = L.i * (uint32_t)(kRec * 4) + (uint32_t)(C_MID * 4);   // the sweeps' start: words C_MID .. C_MID + 12 (+ 3 unused) = four 16-byte pieces
+                    uint32_t awake_bits;
+                    roll_pack_common(r, X.f, awake_bits);
+                    const uint32_t flags = (X.f.flags & (F_GAME_OVER | F_LEG0 | F_LEG1 | F_HAS_WORLD | F_DETERMINISTIC | F_STEPPED | F_PREV_SOME)) | awake_bits;
+                    r.w[C_FLAGS] = flags | F_RESUME | ((moved & 7u) << 9);
+                    r.w[C_PREV] = as_u32(X.e.prev_shaping);                          // (unchanged by the unfinished step; the record may be older than the registers)
+                    r.w[C_WIND] = (uint32_t)X.e.wind_idx; r.w[C_TORQUE] = (uint32_t)X.e.torque_idx;
+                    r.w[C_STEP] = X.e.step; r.w[C_EPISODE] = X.e.episode; r.w[C_SEQ] = X.seq_word;
+                    roll_rec_store(rs, X.i, r);
+                    const uint32_t off = X.i * (uint32_t)(kRec * 4) + (uint32_t)(C_MID * 4);   // the sweeps' start: words C_MID .. C_MID + 12 (+ 3 unused) = four 16-byte pieces
 #pragma unroll
-                for (int b = 0; b < 3; ++b)
-                    __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(L.f.b[b].sw.c0.x), as_u32(L.f.b[b].sw.c0.y), as_u32(L.f.b[b].sw.a0), as_u32(0.0f)}, rs, off + 16u * b, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(0.0f), 0u, 0u, 0u}, rs, off + 48u, 0, 16);
-                P.route = ROLL_TO_CONTACT; P.ent = (L.t << 24) | L.i;   // same step index: the step is not finished
-                L.have = false;
+                    for (int b = 0; b < 3; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(X.f.b[b].sw.c0.x), as_u32(X.f.b[b].sw.c0.y), as_u32(X.f.b[b].sw.a0), as_u32(0.0f)}, rs, off + 16u * b, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(ll_u32x4{as_u32(0.0f), 0u, 0u, 0u}, rs, off + 48u, 0, 16);
+                    P[z].route = ROLL_TO_LIGHT; P[z].ent = (X.t << 24) | X.i;   // same step index: the step is not finished
+                    X.have = false;
+                }
+            } else if (declined[z]) {
+                if (!X.fresh) atomicOr(d.err, DEV_ERR_INTERNAL);   // (a stepped environment has no pending proxies)
+                P[z].route = ROLL_TO_LIGHT; P[z].ent = (X.t << 24) | X.i;
+                X.have = false;
             }
-        } else if (declined) {
-            if (!L.fresh) atomicOr(d.err, DEV_ERR_INTERNAL);   // (a stepped environment has no pending proxies)
-            P.route = ROLL_TO_CONTACT; P.ent = (L.t << 24) | L.i;
-            L.have = false;
+            n_done += (uint32_t)__popcll(__ballot(is_done));
         }
-        finished += (uint32_t)__popcll(__ballot(is_done));
+        finished += n_done;
         const long long ts4 = wall_clock64();
         st.v[RS_T_FREE_FINISH] += (unsigned long long)(ts4 - ts3);
-        // (6) what the free-flight semaphore has granted: ring positions for it, then fill the lanes that were vacant before the sweeps
+        // (6) what the free-flight semaphore has granted: ring positions for it, then fill the slots that were vacant before the sweeps
         if (claim_want > 0) {
             st.v[RS_N_REFILLS] += 1ull;
             const int got = rq_sem_got(q, RQ_FREE, __builtin_amdgcn_readfirstlane(claim_old), claim_want);
@@ -695,27 +751,20 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
                 uint32_t h = 0u;
                 if (lane == 0) h = atomicAdd(rq_ctl(q, RC_HEAD + RQ_FREE), (uint32_t)got);
                 h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-                if (rotate) {   // everyone still on board goes back to the queue (record written through if it was stepped here) ...
-                    if (L.have) {
-                        if (!L.fresh) {
-                            RollRec r;
-                            roll_pack_store(r, L.f, L.e, L.f.flags, L.seq_word);
-                            roll_rec_store(rs, L.i, r);
-                        }
-                        P.route = ROLL_TO_FREE; P.ent = (L.t << 24) | L.i;
-                        L.have = false;
-                    }
+                if (rotate) {   // everyone still on board goes back to the queue ...
+#pragma unroll
+                    for (int z = 0; z < kRollPer; ++z) { leave_for_queue(L[z], P[z]); vac[z] = ~0ull; }
                     on_board = 0u;
                     st.v[RS_N_ROTATIONS] += 1ull;
                 }
-                fill(h, got, rotate ? ~0ull : vac);   // ... and the waiting ones come on board
+                fill(h, got, vac);   // ... and the waiting ones come on board
             }
         }
         on_board += 1u;
         f_avail = __builtin_amdgcn_readlane((int)seen, RQ_FREE); c_avail = __builtin_amdgcn_readlane((int)seen, RQ_CONTACT); l_avail = __builtin_amdgcn_readlane((int)seen, RQ_LIGHT); t_avail = __builtin_amdgcn_readlane((int)seen, RQ_TOI);
         f_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_FREE); c_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_CONTACT); l_headt = __builtin_amdgcn_readlane((int)seen, RC_HEADT + RQ_LIGHT);
         st.v[RS_T_FREE_QUEUE] += (unsigned long long)((wall_clock64() - ts4) + (ts3 - tq0));
-        // (7) what the contact semaphore has granted: everyone leaves the registers, the batch goes to the caller
+        // (7) what the contact-path semaphore has granted: everyone leaves the registers, the batch goes to the caller
         if (cclaim_want > 0) {
             const int m = rq_sem_got(q, cclaim_which, __builtin_amdgcn_readfirstlane(cclaim_old), cclaim_want);
             if (m > 0) {
@@ -723,26 +772,10 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
                 if (lane == 0) h = atomicAdd(rq_ctl(q, RC_HEAD + cclaim_which), (uint32_t)m);
                 h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
                 const uint32_t ent = rq_take(d, q, cclaim_which, h, m);
-                // the pending ones are joined by the residents (their records written through if they have been stepped here)
-                unsigned long long pm2[5];
-                if (__any(P.route != ROLL_NONE)) {
-                    const uint32_t ret = roll_dispatch_issue(q, P, pm2);
-                    rq_drain();
-                    roll_dispatch_complete(d, q, P, pm2, ret);
-                }
-                if (L.have) {
-                    if (!L.fresh) {
-                        RollRec r;
-                        roll_pack_store(r, L.f, L.e, L.f.flags, L.seq_word);
-                        roll_rec_store(rs, L.i, r);
-                    }
-                    P.route = ROLL_TO_FREE; P.ent = (L.t << 24) | L.i;
-                }
-                {
-                    const uint32_t ret = roll_dispatch_issue(q, P, pm2);
-                    rq_drain();
-                    roll_dispatch_complete(d, q, P, pm2, ret);
-                }
+                flush_pending();   // the pending ones first, then the residents
+#pragma unroll
+                for (int z = 0; z < kRollPer; ++z) leave_for_queue(L[z], P[z]);
+                flush_pending();
                 __syncthreads();
                 if (lane < m) S.late[lane] = ent;
                 __syncthreads();
