@@ -630,6 +630,26 @@ def main():
                                          "steps": ksteps, "alg_bytes_per_env_step": 10 + 40 / RING,
                                          "note": "mgym_rollout: K=16 steps per launch, bit-identical to 16 mgym_step calls"}
         st.close()
+        # ... and under the in-kernel linear policy (mgym_rollout_linear): the policy loop of `cartpole_torch_policy_loop` below without leaving the registers
+        st = Stepper(mg, torch, "cartpole", 1 << 20, local_rank, args.seed + 10, 0, stream, "fused", "eager")
+        rw = torch.empty((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.float32)
+        dn = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        tr = torch.zeros((RING, st.n), device=f"cuda:{local_rank}", dtype=torch.uint8)
+        stream.wait_stream(torch.cuda.current_stream(local_rank))
+        pol = [0.1, 0.5, 1.0, 1.0, 0.0]
+        for _ in range(4):
+            st.env.rollout_linear_device(pol, RING, None, None, rw, dn, tr)
+        st.env.sync()
+        st.env.timer_start()
+        reps = 50
+        for _ in range(reps):
+            st.env.rollout_linear_device(pol, RING, None, None, rw, dn, tr)
+        ms = st.env.timer_stop()
+        st.env.sync()
+        extra["cartpole_rollout_linear_policy_K16"] = {"env_steps_per_s": st.n * reps * RING / (ms * 1e-3), "us_per_step": ms * 1e3 / (reps * RING), "n_envs": st.n, "steps": reps * RING,
+                                                       "note": "mgym_rollout_linear: policy a = (w . obs + b > 0) evaluated in the rollout kernel (no action table, no policy launch); "
+                                                               "equal to a stepping loop with the same weights and to the oracle (tests/test_gpu_classic.py)"}
+        st.close()
         # BASELINE configs[2] as SURVEY §8d C3 defines it: MountainCar-v0 and MountainCarContinuous-v0, 1 048 576 envs each, separate handles on
         # separate streams, both in flight at once (graph replay on each stream, common start, the later end counts)
         s_a, s_b = stream, torch.cuda.Stream(device=local_rank)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MGYM_ABI_VERSION 3
+#define MGYM_ABI_VERSION 4
 
 typedef struct mgym_env mgym_env;
 
@@ -155,6 +155,15 @@ int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, 
  * `action_space().sample()` then `step()` (cartpole.rs:251-348, 350-356). */
 int mgym_rollout_uniform(mgym_env *env, uint64_t policy_seed, int32_t K, void *actions_out, float *obs_out,
                          float *reward_out, uint8_t *done_out, uint8_t *trunc_out);
+
+/* mgym_rollout under an on-device LINEAR policy (SURVEY §8f-1 "policy hook"; §8f-4: the step either side of the path — policy inference consumes the
+ * observation, produces the action): at every step env i takes action 1 if ((w[0]*x + w[1]*x_dot) + w[2]*theta) + w[3]*theta_dot + b > 0 (f32, evaluated in
+ * exactly that order, nothing fused), else 0, on the observation it holds BEFORE the step — the loop a trainer's rollout collector runs
+ * (`let a = policy(&obs); let info = env.step(a)`, cartpole.rs:251-348) without leaving the GPU's registers.  `policy` is a HOST pointer to obs_dim weights
+ * followed by the bias (5 floats, read during the call).  actions_out ([K][n_envs] uint32, may be NULL) receives the actions taken.  CartPole only; n_envs a
+ * multiple of 4. */
+int mgym_rollout_linear(mgym_env *env, const float *policy, int32_t K, void *actions_out, float *obs_out,
+                        float *reward_out, uint8_t *done_out, uint8_t *trunc_out);
 
 /* Number of env-steps of this handle that returned done or truncated since mgym_create (StepInfo.done / .truncated,
  * cartpole.rs:300-305): accumulated inside the step kernels by __ballot/popcount reductions of the done mask,

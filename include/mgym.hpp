@@ -59,6 +59,9 @@ class VecGym {
     }
     void sync() { check(mgym_sync(env_)); }
     // K fused steps under the on-device uniform random policy (CartPole); actions_out may be null
+    void rollout_linear(const float* policy, int K, void* actions_out, float* obs, float* reward, uint8_t* done, uint8_t* trunc) {
+        check(mgym_rollout_linear(env_, policy, K, actions_out, obs, reward, done, trunc));
+    }
     void rollout_uniform(uint64_t policy_seed, int K, void* actions_out, float* obs, float* reward, uint8_t* done, uint8_t* trunc) {
         check(mgym_rollout_uniform(env_, policy_seed, K, actions_out, obs, reward, done, trunc));
     }

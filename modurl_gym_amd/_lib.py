@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mgym_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgym_rollout": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "mgym_rollout_uniform": (C.c_int, [_vp, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mgym_rollout_linear": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "mgym_episode_count": (C.c_int, [_vp, _u64p]),
     "mgym_observation": (C.c_int, [_vp, C.POINTER(_vp), _u64p]),
     "mgym_observation_aos": (C.c_int, [_vp, _vp]),
@@ -90,7 +91,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mgym_abi_version() != 3:
+    if lib.mgym_abi_version() != 4:
         raise OSError("libmgym.so ABI version mismatch")
     _lib = lib
     return lib

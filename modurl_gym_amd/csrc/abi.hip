@@ -250,6 +250,14 @@ int mgym_rollout_uniform(mgym_env* env, uint64_t policy_seed, int32_t K, void* a
     return e->rollout_uniform(policy_seed, K, actions_out, obs_out, reward_out, done_out, trunc_out);
 }
 
+int mgym_rollout_linear(mgym_env* env, const float* policy, int32_t K, void* actions_out, float* obs_out, float* reward_out,
+                        uint8_t* done_out, uint8_t* trunc_out) {
+    ENV_OR_FAIL(env);
+    if (K < 0) return bad_arg("mgym_rollout_linear: K < 0");
+    if (!policy) return bad_arg("mgym_rollout_linear: policy is NULL");
+    return e->rollout_linear(policy, K, actions_out, obs_out, reward_out, done_out, trunc_out);
+}
+
 int mgym_episode_count(mgym_env* env, uint64_t* finished) {
     ENV_OR_FAIL(env);
     if (!finished) return bad_arg("mgym_episode_count: NULL");

@@ -271,7 +271,8 @@ cartpole_step_kernel(CartPoleDev d, const uint32_t* __restrict__ act, float* __r
 }
 
 // policy of a fused rollout: actions from the caller's [K][n] table, or drawn on the device
-enum { ROLL_TABLE = 0, ROLL_UNIFORM = 1 };
+enum { ROLL_TABLE = 0, ROLL_UNIFORM = 1, ROLL_LINEAR = 2 };
+struct LinearPolicy { float w[4], b; };   // action = ((w0 x + w1 x_dot) + w2 theta) + w3 theta_dot + b > 0 (mgym_rollout_linear)
 
 // Fused K-step rollout (mgym_rollout / mgym_rollout_uniform): one lane keeps its 4 environments in registers for
 // K steps; per step it reads one 16-B action word (or takes the next bit of its Philox policy stream) and writes
@@ -279,7 +280,7 @@ enum { ROLL_TABLE = 0, ROLL_UNIFORM = 1 };
 // cartpole_step_kernel by construction: same per-wave function.
 template <bool EULER, bool SB, bool RESET, int POLICY>
 __global__ void __launch_bounds__(kBlock)
-cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_t* __restrict__ act_out, uint64_t policy_seed, uint32_t policy_call,
+cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_t* __restrict__ act_out, uint64_t policy_seed, uint32_t policy_call, LinearPolicy lin,
                         int K, float* __restrict__ obs_out, float* __restrict__ rew, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
     __shared__ WaveResetScratch<4> lds_[RESET ? kWaves : 1];
     constexpr uint64_t kPerBlock = (uint64_t)kBlock * 4;
@@ -317,6 +318,11 @@ cartpole_rollout_kernel(CartPoleDev d, const uint32_t* __restrict__ act, uint32_
             float r[4];
             if (POLICY == ROLL_TABLE) {
                 if (in) { const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ra, off4, so, 2); a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w; }
+            } else if (POLICY == ROLL_LINEAR) {
+                // linear policy on the observation the env holds before the step, in the documented order (the file is compiled with -ffp-contract=off)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = ((((lin.w[0] * s[k].x + lin.w[1] * s[k].xd) + lin.w[2] * s[k].th) + lin.w[3] * s[k].thd) + lin.b > 0.0f) ? 1u : 0u;
+                if (in && act_out) __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], a[2], a[3]}, ra, off4, so, 2);
             } else {
                 // uniform random policy: env i takes bit (t % 32) of word (i % 4) of Philox(policy_seed; lane's first
                 // global env id, policy_call, SLOT_POLICY + t / 32) — one Philox evaluation per lane per 32 steps
@@ -516,10 +522,10 @@ struct CartPoleEnv final : Env {
 
     template <int POLICY>
     void launch_rollout(dim3 g, const uint32_t* act, uint32_t* act_out, uint64_t pseed, uint32_t pcall, int K, float* obs_out, float* reward,
-                        uint8_t* done, uint8_t* trunc) {
+                        uint8_t* done, uint8_t* trunc, LinearPolicy lin = LinearPolicy{}) {
         const bool eu = cfg.is_euler, sb = cfg.sutton_barto_reward, rs = auto_reset;
         dim3 b(kBlock);
-#define MGYM_CP_ROLL(E, S, R) hipLaunchKernelGGL((cartpole_rollout_kernel<E, S, R, POLICY>), g, b, 0, stream, dev, act, act_out, pseed, pcall, K, obs_out, reward, done, trunc)
+#define MGYM_CP_ROLL(E, S, R) hipLaunchKernelGGL((cartpole_rollout_kernel<E, S, R, POLICY>), g, b, 0, stream, dev, act, act_out, pseed, pcall, lin, K, obs_out, reward, done, trunc)
         if (eu && !sb) { if (rs) MGYM_CP_ROLL(true, false, true); else MGYM_CP_ROLL(true, false, false); }
         else if (eu) { if (rs) MGYM_CP_ROLL(true, true, true); else MGYM_CP_ROLL(true, true, false); }
         else if (!sb) { if (rs) MGYM_CP_ROLL(false, false, true); else MGYM_CP_ROLL(false, false, false); }
@@ -547,6 +553,22 @@ struct CartPoleEnv final : Env {
             return MGYM_ERR_BAD_ARG;
         }
         launch_rollout<ROLL_UNIFORM>(dim3(grid_for(n / 4)), nullptr, ao, policy_seed, policy_calls++, K, obs_out, reward, done, trunc);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    int rollout_linear(const float* policy, int K, void* actions_out, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        uint32_t* ao = static_cast<uint32_t*>(actions_out);
+        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16) ||
+            (uint64_t)K * n * 4 >= (1ull << 32)) {
+            set_last_error("mgym_rollout_linear: n_envs must be a multiple of 4, the buffers 16-byte aligned, and K * n_envs below 2^30");
+            return MGYM_ERR_BAD_ARG;
+        }
+        LinearPolicy lin;
+        for (int q = 0; q < 4; ++q) lin.w[q] = policy[q];
+        lin.b = policy[4];
+        launch_rollout<ROLL_LINEAR>(dim3(grid_for(n / 4)), nullptr, ao, 0, 0, K, obs_out, reward, done, trunc, lin);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

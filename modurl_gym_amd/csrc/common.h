@@ -67,6 +67,11 @@ struct Env {
         set_last_error("mgym_rollout_uniform: not available for this environment family");
         return MGYM_ERR_BAD_ARG;
     }
+    // K fused steps under an on-device linear policy; policy = obs_dim weights + bias (host)
+    virtual int rollout_linear(const float*, int, void*, float*, float*, uint8_t*, uint8_t*) {
+        set_last_error("mgym_rollout_linear: not available for this environment family");
+        return MGYM_ERR_BAD_ARG;
+    }
     virtual int observation(const float** obs, uint64_t* col_stride) = 0;
     virtual int get_state(void* blob) = 0;
     virtual int set_state(const void* blob) = 0;

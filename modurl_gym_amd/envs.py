@@ -184,6 +184,24 @@ class VecEnv:
         _check(self._lib.mgym_rollout_uniform(self._h, int(policy_seed), int(K), _ptr(actions_out), _ptr(obs_out), _ptr(reward_out),
                                               _ptr(done_out), _ptr(trunc_out)))
 
+    def rollout_linear_device(self, policy, K, actions_out=None, obs_out=None, reward_out=None, done_out=None, trunc_out=None):
+        """K fused steps under the on-device linear policy (mgym_rollout_linear; CartPole): policy = obs_dim weights + bias (host floats)."""
+        pol = (C.c_float * (self.obs_dim + 1))(*[float(v) for v in policy])
+        _check(self._lib.mgym_rollout_linear(self._h, pol, int(K), _ptr(actions_out), _ptr(obs_out), _ptr(reward_out), _ptr(done_out),
+                                             _ptr(trunc_out)))
+
+    def rollout_linear(self, policy, K):
+        """host-array form: -> (actions [K, n], obs [K, obs_dim, n], reward [K, n], done, trunc)"""
+        n = max(self.n, 1)
+        da = DeviceArray((K, n), np.uint32, self.device)
+        do = DeviceArray((K, self.obs_dim, n), np.float32, self.device)
+        dr = DeviceArray((K, n), np.float32, self.device)
+        dd, dt = DeviceArray((K, n), np.uint8, self.device), DeviceArray((K, n), np.uint8, self.device)
+        self.rollout_linear_device(policy, K, da, do, dr, dd, dt)
+        self.sync()
+        sh = lambda x, shape: x.numpy().reshape(-1)[: int(np.prod(shape))].reshape(shape)
+        return (sh(da, (K, self.n)), sh(do, (K, self.obs_dim, self.n)), sh(dr, (K, self.n)), sh(dd, (K, self.n)), sh(dt, (K, self.n)))
+
     def rollout_uniform(self, policy_seed, K):
         """host-array form: -> (actions [K, n], obs [K, obs_dim, n], reward [K, n], done, trunc)"""
         n = max(self.n, 1)

@@ -7,7 +7,7 @@ pub struct mgym_env {
     _opaque: [u8; 0],
 }
 
-pub const MGYM_ABI_VERSION: c_int = 3;
+pub const MGYM_ABI_VERSION: c_int = 4;
 
 pub const MGYM_OK: c_int = 0;
 pub const MGYM_ERR_INVALID_ACTION: c_int = 1;
@@ -87,6 +87,16 @@ unsafe extern "C" {
     pub fn mgym_rollout_uniform(
         env: *mut mgym_env,
         policy_seed: u64,
+        k: i32,
+        actions_out: *mut c_void,
+        obs_out: *mut f32,
+        reward_out: *mut f32,
+        done_out: *mut u8,
+        trunc_out: *mut u8,
+    ) -> c_int;
+    pub fn mgym_rollout_linear(
+        env: *mut mgym_env,
+        policy: *const f32,
         k: i32,
         actions_out: *mut c_void,
         obs_out: *mut f32,

@@ -142,6 +142,22 @@ impl VecGym {
         check(unsafe { mgym_rollout(self.env, actions, k, obs, reward, done, truncated) })
     }
 
+    /// K fused steps under an on-device linear policy (CartPole; `mgym_rollout_linear`): `policy` = 4 weights + bias; the loop
+    /// `let a = policy(&obs); env.step(a)` of cartpole.rs:251-348 without leaving the GPU.
+    /// # Safety
+    /// the output pointers are device pointers of `[K][n]` (`[K][4][n]` for `obs`) elements, or null.
+    pub unsafe fn rollout_linear(
+        &mut self,
+        policy: &[f32; 5],
+        k: i32,
+        actions_out: *mut c_void,
+        obs: *mut f32,
+        reward: *mut f32,
+        done: *mut u8,
+        truncated: *mut u8,
+    ) -> Result<(), MgymError> {
+        check(unsafe { mgym_rollout_linear(self.env, policy.as_ptr(), k, actions_out, obs, reward, done, truncated) })
+    }
     /// K fused steps under the on-device uniform random policy (CartPole; `mgym_rollout_uniform`): no action table.
     /// `actions_out` (`[K][n]` u32, may be null) receives the drawn actions.
     #[allow(clippy::too_many_arguments)]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = _lib.load()
-    assert lib.mgym_abi_version() == 3
+    assert lib.mgym_abi_version() == 4
     cfg = _lib.Config()
     assert lib.mgym_default_config(mg.LUNARLANDER, C.byref(cfg)) == _lib.OK
     # reference builder defaults: cartpole.rs:39-40, mountain_car.rs:33, lunar_lander.rs:282-285

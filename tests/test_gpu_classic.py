@@ -617,3 +617,37 @@ def test_discrete_actions_must_be_integers():
     with pytest.raises(mg.InvalidActionError):
         env.step(np.array([True, False, True, False]))
     env.step(np.array([0, 1, 1, 0], np.int64))                 # any integer dtype is fine
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_rollout_linear_policy_equals_a_stepping_loop_with_the_same_weights_and_the_oracle(auto_reset):
+    """mgym_rollout_linear (SURVEY 8f-1 policy hook, 8f-4 the step either side of the path): the in-kernel policy
+    a = (((w0 x + w1 x_dot) + w2 theta) + w3 theta_dot) + b > 0, evaluated on the observation the env holds before the step, must give the actions,
+    observations, rewards and flags of a loop that computes the same expression in f32 (numpy: each operation rounded, nothing fused) and calls
+    mgym_step, and of the oracle driven by those actions.  Caller loop it fuses: cartpole.rs:251-348 with the policy in front."""
+    n, K = 8192, 48
+    pol = np.array([0.1, 0.5, 1.0, 1.0, -0.003], np.float32)
+    fused = mg.VecEnv(mg.CARTPOLE, n, seed=21, auto_reset=auto_reset)
+    loop = mg.VecEnv(mg.CARTPOLE, n, seed=21, auto_reset=auto_reset)
+    ref = ora.OracleVec(ora.CARTPOLE, n, seed=21)
+    obs = loop.reset()
+    assert np.array_equal(fused.reset(), obs) and np.array_equal(ref.reset(nthreads=8), obs)
+    for rnd in range(3):
+        acts, gobs, grew, gdone, gtrunc = fused.rollout_linear(pol, K)
+        for t in range(K):
+            lin = ((pol[0] * obs[0] + pol[1] * obs[1]) + pol[2] * obs[2]) + pol[3] * obs[3]     # float32 arrays: every operation rounds to f32
+            a = ((lin + pol[4]) > 0).astype(np.uint32)
+            assert np.array_equal(acts[t], a), f"round {rnd} step {t}: actions"
+            o, r, d, tr = loop.step(a)
+            eo, er, ed, et = ref.step(a, nthreads=8)
+            if auto_reset:
+                m = (ed | et).astype(np.uint8)
+                ro = ref.reset(mask=m, nthreads=8)
+                eo = np.where(m.astype(bool)[None, :], ro, eo)
+            for g, e, x, nm in zip((gobs[t], grew[t], gdone[t], gtrunc[t]), (o, r, d, tr), (eo, er, ed, et), ("obs", "reward", "done", "truncated")):
+                assert np.array_equal(g, e), f"round {rnd} step {t}: {nm} vs the stepping loop"
+                assert np.array_equal(g, x), f"round {rnd} step {t}: {nm} vs the oracle"
+            obs = o
+    assert fused.episode_count() == loop.episode_count() > 0
+    with pytest.raises(mg.MgymError):
+        mg.VecEnv(mg.MOUNTAINCAR, 8).rollout_linear(pol[:3], 4)   # CartPole only
