@@ -45,7 +45,7 @@ constexpr uint32_t kWorkReset = 0x80000000u;  // worklist entry = env index | kW
 //   L_TOI0 + r   envs whose world.step still has time-of-impact sub-steps to do after round r (see ll_toi_kernel)
 constexpr int kToiRounds = 4;
 //   C_NEXT       (a counter only) the length of the NEXT step's L_GENERAL while ll_epilogue_kernel is filling it; C_TICKET: its block ticket
-enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_TICKET, C_TICKET2,
+enum { L_GENERAL = 0, L_GENERAL_T = 1, L_RESET = 2, L_RESET_SLOW = 3, L_LATE = 4, L_RESET_DIRECT = 5, L_TOI0 = 6, C_NEXT = L_TOI0 + kToiRounds, C_NEXT_T /* ... and of its touching end */, C_TICKET, C_TICKET2,
        L_COUNT, L_PREP = L_COUNT, L_PREP_SLOW, L_LISTS };  // (the counts of the lists below L_COUNT are zeroed by rebuild_list() / at the start of every call of the unfused order)
 
 struct LLIo {
@@ -90,8 +90,8 @@ __device__ __forceinline__ void ll_push_back(const LLDev& d, int which_list, int
 // block-aggregated append for kernels whose every wave appends (ll_classify_kernel): ONE atomic per block and list — thousands
 // of per-wave atomics on one counter serialise at ~11 ns each.  All threads of the block must call it (it synchronises);
 // `s_cnt` is block-shared scratch for (blockDim.x / 64 + 1) words.
-__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt, int which_count = -1) {
-    if (which_count < 0) which_count = which;   // (the epilogue fills next step's L_GENERAL under the counter C_NEXT)
+__device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool want, uint32_t entry, uint32_t* s_cnt, int which_count = -1, bool from_back = false) {
+    if (which_count < 0) which_count = which;   // (the epilogue fills next step's L_GENERAL under the counters C_NEXT / C_NEXT_T)
     const unsigned long long mask = __ballot(want);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     __syncthreads();  // s_cnt may still be read by the previous call
@@ -103,7 +103,10 @@ __device__ __forceinline__ void ll_push_block(const LLDev& d, int which, bool wa
         s_cnt[nw] = tot ? atomicAdd(d.work_count + which_count, tot) : 0u;
     }
     __syncthreads();
-    if (want) d.work_list[(uint64_t)which * d.n_pad + s_cnt[nw] + s_cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    if (want) {
+        const uint32_t at = s_cnt[nw] + s_cnt[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        d.work_list[(uint64_t)which * d.n_pad + (from_back ? d.n_pad - 1u - at : at)] = entry;
+    }
 }
 
 // done-mask reduction for mgym_episode_count: ballot + popcount per wave pass, one fire-and-forget atomic per wave at the end

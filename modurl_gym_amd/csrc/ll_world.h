@@ -937,7 +937,11 @@ LL_NOINLINE void toi_sweeps(CSolver& cs, Vel& vd_io LL_WI_PARAM) {
     const Vel v_in = vd; const VConstraint r0_in = r0, r1_in = r1;
 #endif
     bool can_stop = cs.count <= 2;  // constraints beyond the two register-resident ones are not compared
+#ifdef LL_TOI_NO_SETTLED_EXIT   // A/B builds (make EXTRA=-DLL_TOI_NO_SETTLED_EXIT): the settled-velocity proof is never tried, fixed points and cycles still end the loop
+    const bool can_settle = false;
+#else
     const bool can_settle = can_stop && (!h0 || r0.pointCount == 1) && (!h1 || r1.pointCount == 1);
+#endif
     int settle_at = 2;              // the proof is tried when the velocity has not moved during a sweep, with exponential back-off
     auto state_now = [&]() {
         ToiSweepState st;

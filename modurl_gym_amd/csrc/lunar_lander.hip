@@ -231,8 +231,15 @@ __device__ __forceinline__ void ll_emit(const LLDev& d, const LLIo& io, uint64_t
 // ll_toi_kernel.
 // where a wave of the contact path takes its environments from: entry q of a list that is filled from both ends
 // (c0 entries from the front — rounded up to c0_up slots —, c1 from the back, `back` = index of the last slot)
-struct ContactList { const uint32_t* list; uint64_t back, c0, c0_up, c1; bool spread; };
+// back_first (the product's bucketing, 64-lane blocks): the c1 touching envs from the back come FIRST (rounded up to c0_up slots, which then
+// holds c1's round-up), the others behind them — blocks start in list order, so the long blocks start first and the short ones fill the end
+struct ContactList { const uint32_t* list; uint64_t back, c0, c0_up, c1; bool spread, back_first; };
+LLD uint64_t ll_list_total(const ContactList& L) { return L.back_first ? L.c0_up + L.c0 : L.c0_up + L.c1; }
+LLD bool ll_list_has(const ContactList& L, uint64_t q, uint64_t total) {
+    return L.back_first ? (q < L.c1 || (q >= L.c0_up && q < total)) : (q < L.c0 || (q >= L.c0_up && q < total));
+}
 LLD uint64_t ll_list_entry(const ContactList& L, uint64_t q, uint64_t total) {
+    if (L.back_first) return q < L.c1 ? L.list[L.back - q] : L.list[q - L.c0_up];
     if (L.spread) {
         const uint64_t h0 = q * L.c1 / total, h1 = (q + 1) * L.c1 / total;
         return h1 > h0 ? L.list[L.back - h0] : L.list[q - h0];
@@ -259,10 +266,10 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
     CSolverMem mem;
     mem.vc = &S.vc[own]; mem.vc_stride = BLK; mem.vc_near = d.vc_near < kVcNearLds ? d.vc_near : kVcNearLds; mem.pc = l_pc; mem.pc_stride = 1; mem.cap = kSolverCap;
     mem.vc_far = far_lane0 + own; mem.vc_far_stride = far_stride;
-    const uint64_t total = CL.c0_up + CL.c1;
+    const uint64_t total = ll_list_total(CL);
     for (uint64_t q0 = q_first; q0 < total; q0 += q_stride) {  // block-uniform
         const uint64_t q = q0 + threadIdx.x;
-        const bool have = env_lane && (int)threadIdx.x < fill && (q < CL.c0 || (q >= CL.c0_up && q < total));
+        const bool have = env_lane && (int)threadIdx.x < fill && ll_list_has(CL, q, total);
         uint64_t i = 0;
         bool to_toi = false, to_reset = false, is_done = false;
         bool stepping = false;      // this lane is inside world.step
@@ -396,7 +403,8 @@ ll_contact_kernel(LLDev d, LLIo io, int toi_budget, int which) {
     // that take time-of-impact sub-steps (59 % of them against 12 % of the others) — are dealt out evenly over the waves:
     // of the first q entries floor(q * c1 / total) come from the touching list
     CL.spread = d.bucket == 2;
-    CL.c0_up = CL.spread ? CL.c0 : (CL.c0 + BLK - 1) / BLK * BLK;
+    CL.back_first = d.bucket == 1;
+    CL.c0_up = CL.spread ? CL.c0 : ((CL.back_first ? CL.c1 : CL.c0) + BLK - 1) / BLK * BLK;
     // the two contact launches of the overlapped order run at the same time: each has its own slice of the workspace
     ll_contact_body<BLK>(d, io, toi_budget, CL, (uint64_t)blockIdx.x * BLK, (uint64_t)gridDim.x * BLK,
                          (which == L_LATE ? d.vc_far_late : d.vc_far) + (uint64_t)blockIdx.x * BLK, (int)(gridDim.x * BLK), S, not_reset, overflow, finished);
@@ -616,7 +624,7 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
 #endif
     if (blockIdx.x < g_contact) {
         ContactList CL;
-        CL.list = d.work_list + (uint64_t)L_GENERAL * d.n_pad; CL.back = 0; CL.c0 = d.work_count[L_GENERAL]; CL.c1 = 0; CL.spread = false;
+        CL.list = d.work_list + (uint64_t)L_GENERAL * d.n_pad; CL.back = 0; CL.c0 = d.work_count[L_GENERAL]; CL.c1 = 0; CL.spread = false; CL.back_first = false;
         CL.c0_up = (CL.c0 + BLK - 1) / BLK * BLK;
         if (blockIdx.x == 0 && threadIdx.x == 0) { d.work_count[L_RESET_DIRECT] = 0u; d.work_count[L_RESET_SLOW] = 0u; }   // (consumed by the last launches of the previous call)
         // LANES PER BLOCK by the length of the list: the step ends with the slowest contact block, and a block's chain grows with the lanes
@@ -657,7 +665,7 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
                 }
                 __syncthreads();
                 ContactList CL;
-                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)at; CL.c1 = 0; CL.spread = false; CL.c0_up = CL.c0;
+                CL.list = S.late; CL.back = 0; CL.c0 = (uint64_t)at; CL.c1 = 0; CL.spread = false; CL.back_first = false; CL.c0_up = CL.c0;
                 ll_contact_body<BLK>(d, io, -1, CL, 0, BLK, d.vc_far_late + (uint64_t)fb * BLK, (int)(g_free * BLK), S, not_reset, overflow, finished);
                 __syncthreads();
             }
@@ -789,15 +797,17 @@ ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < d.n; base += stride) {  // block-uniform trip count
         const uint64_t i = base + tid;
-        bool to_general = false;
+        bool to_general = false, touching = false;
         if (i < d.n) {
             if (d.env_class[i] != 2) {
                 const uint32_t flags = ST(C_FLAGS);
                 to_general = (flags & F_HAS_WORLD) && !ll_free_eligible(flags);
+                touching = d.bucket && (flags & F_TOUCHING);
             }
             d.env_class[i] = to_general ? 1 : 0;
         }
-        ll_push_block(d, L_GENERAL, to_general, (uint32_t)i, s_cnt, C_NEXT);
+        ll_push_block(d, L_GENERAL, to_general && !touching, (uint32_t)i, s_cnt, C_NEXT);
+        if (d.bucket) ll_push_block(d, L_GENERAL, to_general && touching, (uint32_t)i, s_cnt, C_NEXT_T, true);   // (block-uniform)
     }
     // (No device-scope fence: the list ENTRIES are only read by later kernels, and the counts travel by atomics that this thread has
     // already waited for.  A __threadfence() here costs 90 us per launch — every wave writes back its XCD's L2.)
@@ -806,7 +816,7 @@ ll_epilogue_kernel(LLDev d, const uint32_t* __restrict__ shadow, const float* __
         const uint32_t ticket = atomicAdd(d.work_count + C_TICKET, 1u);
         if (ticket == gridDim.x - 1) {   // every other block has added its count (its thread 0 waited for that atomic before taking a ticket)
             d.work_count[L_GENERAL] = atomicExch(d.work_count + C_NEXT, 0u);
-            d.work_count[L_GENERAL_T] = 0u; d.work_count[L_LATE] = 0u; d.work_count[L_RESET] = 0u;
+            d.work_count[L_GENERAL_T] = atomicExch(d.work_count + C_NEXT_T, 0u); d.work_count[L_LATE] = 0u; d.work_count[L_RESET] = 0u;
             if (!staged) { d.work_count[L_RESET_SLOW] = 0u; d.work_count[L_RESET_DIRECT] = 0u; }
             d.work_count[C_TICKET] = 0u;
         }
@@ -915,6 +925,13 @@ struct LunarLanderEnv final : Env {
     LLDev dev{};
     bool general_only = getenv("MGYM_LL_GENERAL_ONLY") != nullptr;
     int gen_block = getenv("MGYM_LL_GENERAL_BLOCK") ? atoi(getenv("MGYM_LL_GENERAL_BLOCK")) : 0;   // lanes per block of the contact kernel; 0: by population (init)
+    // the contact list by kind (multi-stream order): -1 by population (init) | 0 in index order | 1 the envs with a touching contact at the back of
+    // the list and taken FIRST, in blocks of their own (the long blocks start first, the short ones fill the end) | 2 (-DLL_DIAG) dealt out evenly.
+    // ms per step, 0 | 1, same box (profiles/r04_lunarlander/contact_list_by_kind.txt): 524 288 envs 1.37 | 1.57 (the step is still its slowest block, and a
+    // block of 64 touching envs is slower than one with a few of them), 655 360: 1.58 | 1.60, 786 432: 2.11 | 1.70, 1 Mi: 2.45 | 2.20, 2 Mi: 5.44 | 4.67
+    // (bound by SIMD occupancy: blocks of one kind keep more of their lanes busy).  The two ends as launches of their own — the touching end in 32-lane
+    // blocks with their helper lanes, the rest in 64-lane blocks — were slower at every size (1 Mi: 2.97): built, measured, not kept.
+    int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : -1;
 #ifdef LL_DIAG
     int toi_block = getenv("MGYM_LL_TOI_BLOCK") ? atoi(getenv("MGYM_LL_TOI_BLOCK")) : 32;          // lanes per block of the time-of-impact round kernels
 #endif
@@ -926,12 +943,11 @@ struct LunarLanderEnv final : Env {
     // heavy lanes (bucketing) lengthens that wave, and follow-up launches serialise the same chain behind launch
     // boundaries and a state round trip.  The alternatives stay selectable for profiling:
 #ifdef LL_DIAG
-    int bucket = getenv("MGYM_LL_BUCKET") ? atoi(getenv("MGYM_LL_BUCKET")) : 0;       // 1: touching / non-touching envs at opposite ends of the worklist
     int toi_first = getenv("MGYM_LL_TOI_FIRST") ? atoi(getenv("MGYM_LL_TOI_FIRST")) : 0;  // with MGYM_LL_TOI_ROUNDS: sub-steps taken inside the contact kernel first
     int toi_rounds = getenv("MGYM_LL_TOI_ROUNDS") ? atoi(getenv("MGYM_LL_TOI_ROUNDS")) : 0;  // 0: none; 1 .. kToiRounds launches of ll_toi_kernel
     int fused_tail = getenv("MGYM_LL_FUSED_TAIL") ? atoi(getenv("MGYM_LL_FUSED_TAIL")) : 1;  // 1 (default): the fused order of step() (ll_epilogue_kernel); needs the overlapped order and none of the profiling knobs
 #else
-    static constexpr int bucket = 0, toi_rounds = 0;
+    static constexpr int toi_rounds = 0;
     int fused_tail = 1;   // (0 only with MGYM_LL_GENERAL_ONLY, the debugging aid that sends every env through ll_general_kernel)
 #endif
     int single_launch = getenv("MGYM_LL_SINGLE_LAUNCH") ? atoi(getenv("MGYM_LL_SINGLE_LAUNCH")) : 1;  // 1 (default): contact path, free-flight path and reset preparation in ONE launch (ll_step_kernel); needs the fused order and 32-lane contact blocks
@@ -1005,15 +1021,20 @@ struct LunarLanderEnv final : Env {
         dev.disp = nullptr;
         dev.n = n; dev.n_pad = n_pad; dev.seed = cfg.seed; dev.env_id_base = cfg.env_id_base; dev.err = d_err; dev.done_count = d_done;
         dev.auto_reset = (cfg.flags & MGYM_FLAG_AUTO_RESET) ? 1 : 0;
-        dev.bucket = bucket;
         dev.resume = resume && !general_only;
         // contact blocks that run at once beside the free-flight role: 900 of the 1 024 one-wave-per-SIMD slots (measured 750 .. 1 000 at
         // 65 536 .. 327 680 envs: flat within 1-2 % from 850 up, profiles/r03_lunarlander/block_lanes_by_population.txt)
         if (contact_blocks < 0) contact_blocks = 900;
         dev.contact_blocks = contact_blocks;
-        fused_tail = fused_tail && overlap && !general_only && toi_rounds == 0 && bucket == 0;
+        fused_tail = fused_tail && overlap && !general_only && toi_rounds == 0;
         dev.fused_tail = fused_tail;
         single_launch = single_launch && fused_tail && gen_block == 32 && resume;
+        if (bucket < 0) bucket = (!single_launch && gen_block == 64 && n >= 688128) ? 1 : 0;
+        if (single_launch) bucket = 0;   // (its contact role deals ONE list out over its blocks)
+#ifndef LL_DIAG
+        if (bucket > 1) bucket = 1;
+#endif
+        dev.bucket = bucket;
         ll_make_const(dev.k, cfg.gravity, cfg.enable_wind, cfg.wind_power, cfg.turbulence_power);
         MGYM_HIP(hipMalloc(&kdev, sizeof(LLConst)));
         MGYM_HIP(hipMemcpyAsync(kdev, &dev.k, sizeof(LLConst), hipMemcpyHostToDevice, stream));
@@ -1362,8 +1383,8 @@ struct LunarLanderEnv final : Env {
                 ev_prep_valid = true;
             }
             MGYM_HIP(hipEventRecord(ev_fork, stream));
-            launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
             MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            launch_contact(stream, gen_block, gb, sd, io, -1, L_GENERAL);
             launch_free(aux, sd, io);
             if (stage && (cap || prep_due)) {   // the preparation the previous step marked: behind the free-flight kernel, beside the late contact launch
                 MGYM_HIP(hipEventRecord(ev_free_done, aux));
@@ -1453,9 +1474,9 @@ struct LunarLanderEnv final : Env {
     // mgym_get_info: the launch structure of this handle and whether its streams really run side by side
     int info(std::string& out) override {
         out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
-               "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) +
+               "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_list_by_kind=" + std::to_string(dev.bucket) + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) +
                "\nknobs=MGYM_LL_GENERAL_BLOCK(32|64) MGYM_LL_SINGLE_LAUNCH MGYM_LL_STAGED_RESET MGYM_LL_STAGED_IN_GRAPH MGYM_LL_CONTACT_BLOCKS MGYM_LL_VC_NEAR MGYM_LL_RESUME MGYM_LL_GENERAL_ONLY "
-               "MGYM_LL_AUX_PRIO MGYM_LL_ROLLOUT MGYM_LL_ROLLOUT_MIN_K MGYM_LL_ROLL_STATS MGYM_LL_ROLL_TRACE" +
+               "MGYM_LL_AUX_PRIO MGYM_LL_BUCKET MGYM_LL_ROLLOUT MGYM_LL_ROLLOUT_MIN_K MGYM_LL_ROLL_STATS MGYM_LL_ROLL_TRACE" +
                "\nrollout=" + (roll_enabled ? "persistent_launch" : "k_steps") + "\nrollout_min_k=" + std::to_string(roll_min_k) + "\nrollout_waves=" + std::to_string(roll_grid) + "\n";
         if (capturing()) { set_last_error("mgym_get_info: the stream is being captured (the call launches probe kernels and synchronises)"); return MGYM_ERR_BAD_ARG; }
         hipStream_t ss[3] = {stream, aux, aux2};

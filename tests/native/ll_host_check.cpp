@@ -48,6 +48,9 @@ int main(int argc, char** argv) {
     const int wind = argc > 3 ? atoi(argv[3]) : 0;
     const int deterministic = argc > 4 ? atoi(argv[4]) : 0;
     const unsigned toi_staged = argc > 5 ? (unsigned)atoi(argv[5]) : 1u;  // 0: the TOI word of the contact cache stays in place (64-lane blocks)
+    // other physics settings than the defaults (the early exits of the sweep loops rest on bounds derived from the constraint masses, not on
+    // these values, and must hold for every setting the builder accepts: lunar_lander.rs:278-296)
+    const float gravity = argc > 6 ? (float)atof(argv[6]) : -10.0f, wind_power = argc > 7 ? (float)atof(argv[7]) : 15.0f, turbulence = argc > 8 ? (float)atof(argv[8]) : 1.5f;
     const uint64_t seed = 77;
     // product side: SoA state exactly as the kernels keep it
     LLDev d;
@@ -56,14 +59,14 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> st((size_t)ll_state_words(d.n_pad), 0u);
     std::vector<float> obsbuf((size_t)8 * d.n_pad, 0.0f);
     d.st = st.data(); d.obs = obsbuf.data();
-    ll_make_const(d.k, -10.0f, wind, 15.0f, 1.5f);
+    ll_make_const(d.k, gravity, wind, wind_power, turbulence);
     d.kd = &d.k;
     PolyTab tab;
     for (int p = 0; p < 2; ++p) { tab.count[p] = d.k.poly_count[p]; for (int q = 0; q < kMaxPoly; ++q) { tab.v[p][q] = d.k.poly_v[p][q]; tab.n[p][q] = d.k.poly_n[p][q]; } }
     // oracle side
     ora_vec_config cfg;
     memset(&cfg, 0, sizeof cfg);
-    cfg.kind = 3; cfg.n_envs = n; cfg.seed = seed; cfg.gravity = -10.0f; cfg.enable_wind = wind; cfg.wind_power = 15.0f; cfg.turbulence_power = 1.5f;
+    cfg.kind = 3; cfg.n_envs = n; cfg.seed = seed; cfg.gravity = gravity; cfg.enable_wind = wind; cfg.wind_power = wind_power; cfg.turbulence_power = turbulence;
     int status = 0;
     ora_vec* ov = ora_vec_new(&cfg, &status);
     std::vector<float> oobs(8 * n), orew(n); std::vector<uint8_t> odone(n), otr(n), mask(n);

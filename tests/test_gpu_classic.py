@@ -626,7 +626,7 @@ def test_rollout_linear_policy_equals_a_stepping_loop_with_the_same_weights_and_
     observations, rewards and flags of a loop that computes the same expression in f32 (numpy: each operation rounded, nothing fused) and calls
     mgym_step, and of the oracle driven by those actions.  Caller loop it fuses: cartpole.rs:251-348 with the policy in front."""
     n, K = 8192, 48
-    pol = np.array([0.1, 0.5, 1.0, 1.0, -0.003], np.float32)
+    pol = np.array([0.1, 0.5, -1.0, -1.0, -0.003], np.float32)   # pushes the wrong way: episodes end within a few dozen steps
     fused = mg.VecEnv(mg.CARTPOLE, n, seed=21, auto_reset=auto_reset)
     loop = mg.VecEnv(mg.CARTPOLE, n, seed=21, auto_reset=auto_reset)
     ref = ora.OracleVec(ora.CARTPOLE, n, seed=21)
@@ -648,6 +648,6 @@ def test_rollout_linear_policy_equals_a_stepping_loop_with_the_same_weights_and_
                 assert np.array_equal(g, e), f"round {rnd} step {t}: {nm} vs the stepping loop"
                 assert np.array_equal(g, x), f"round {rnd} step {t}: {nm} vs the oracle"
             obs = o
-    assert fused.episode_count() == loop.episode_count() > 0
+    assert fused.episode_count() == loop.episode_count() > n // 2   # most envs fell at least once
     with pytest.raises(mg.MgymError):
         mg.VecEnv(mg.MOUNTAINCAR, 8).rollout_linear(pol[:3], 4)   # CartPole only

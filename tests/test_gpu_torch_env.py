@@ -121,3 +121,65 @@ def test_argument_checks():
         env.step(torch.zeros(64, dtype=torch.float32, device=env.device))
     with pytest.raises(mg.InvalidActionError):  # cartpole.rs:252
         env.step(torch.full((64,), 2, dtype=torch.int32, device=env.device), check=True)
+
+
+def test_lunar_lander_steps_captured_by_torch_cuda_graph_at_the_multi_stream_size(monkeypatch):
+    """A capture the engine did not begin itself: `torch.cuda.graph` around `TorchVecEnv.step` at 425 984 envs, the smallest population that
+    runs the multi-stream order (64-lane contact kernel beside the free-flight kernel, helper streams forked from and joined to the capturing
+    stream by events, staged resets prepared beside later steps).  Replays interleaved with eager steps must give the words of a plain handle
+    that computes every reset when the episode ends (MGYM_LL_STAGED_RESET=0) — the pending reset preparations are handed over between eager
+    steps and replays in both directions, and no env that finishes inside a replay may stay unreset.  (Semantics: the reference resets a done
+    env through `reset()` incl. the implicit `step(0)`, /root/reference src/box_2d/lunar_lander.rs:727-917.)"""
+    n, ring = 425984, 4
+    env = mg.TorchVecEnv(mg.LUNARLANDER, n, seed=77, enable_wind=True, auto_reset=True)
+    monkeypatch.setenv("MGYM_LL_STAGED_RESET", "0")
+    ref = mg.VecEnv(mg.LUNARLANDER, n, seed=77, enable_wind=True, auto_reset=True)
+    monkeypatch.delenv("MGYM_LL_STAGED_RESET")
+    assert env.env.info()["launch_order"] == "overlapped" and env.env.info()["staged_resets"] == "1" and ref.info()["staged_resets"] == "0"
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    side = torch.cuda.Stream(env.device)
+    static_a = torch.zeros((ring, n), dtype=torch.int32, device=env.device)
+    keep = [torch.empty(n, dtype=torch.float32, device=env.device) for _ in range(ring)]   # reward of each captured step, copied inside the graph
+    finished = 0
+
+    def eager(steps):
+        nonlocal finished
+        for _ in range(steps):
+            a = torch.randint(0, 4, (n,), generator=gen, dtype=torch.int32)
+            with torch.cuda.stream(side):
+                obs, rew, done, _ = env.step(a.to(env.device, non_blocking=False))
+            side.synchronize()
+            e_obs, e_rew, e_done, _ = ref.step(a.numpy().astype(np.uint32))
+            assert np.array_equal(done.cpu().numpy(), e_done.astype(bool)) and np.array_equal(rew.cpu().numpy().view(np.uint32), e_rew.view(np.uint32))
+            assert np.array_equal(obs.cpu().numpy().view(np.uint32), e_obs.view(np.uint32))
+            finished += int(e_done.sum())
+
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.default_stream(env.device))
+        obs0 = env.reset()
+    side.synchronize()
+    assert np.array_equal(obs0.cpu().numpy(), ref.reset())
+    eager(70)                                  # until contacts, crashes and staged resets are frequent; binds the engine to `side`
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for k in range(ring):
+            _, rew, _, _ = env.step(static_a[k])
+            keep[k].copy_(rew)
+    # the capture itself advanced nothing
+    assert np.array_equal(env.state_numpy().view(np.uint32), ref.get_state().view(np.uint32))
+    for rnd in range(4):
+        for rep in range(2):
+            a = torch.randint(0, 4, (ring, n), generator=gen, dtype=torch.int32)
+            static_a.copy_(a.to(env.device))
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            for k in range(ring):
+                _, e_rew, e_done, _ = ref.step(a[k].numpy().astype(np.uint32))
+                assert np.array_equal(keep[k].cpu().numpy().view(np.uint32), e_rew.view(np.uint32)), f"round {rnd} replay {rep} step {k}"
+                finished += int(e_done.sum())
+        env.check()                            # a finished env without a reset would have raised the sticky internal error
+        assert np.array_equal(env.state_numpy().view(np.uint32), ref.get_state().view(np.uint32)), f"round {rnd}: state blob after the replays"
+        eager(3)
+    assert finished > n // 4
+    env.close(), ref.close()

@@ -30,11 +30,14 @@ def ll_host():
     return _build("ll_host_check.cpp", "ll_host_check", [f"-L{odir}", "-loracle", f"-Wl,-rpath,{odir}"])
 
 
-@pytest.mark.parametrize("n,steps,wind,det,toi_staged", [(64, 300, 0, 1, 1), (256, 400, 0, 0, 1), (256, 400, 1, 0, 1), (256, 300, 1, 0, 0)])
-def test_kernel_source_matches_oracle_on_cpu(ll_host, n, steps, wind, det, toi_staged):
+@pytest.mark.parametrize("n,steps,wind,det,toi_staged,physics", [(64, 300, 0, 1, 1, ()), (256, 400, 0, 0, 1, ()), (256, 400, 1, 0, 1, ()), (256, 300, 1, 0, 0, ()),
+                                                                  (192, 500, 1, 0, 1, (-3.5, 19.5, 1.95)), (192, 300, 1, 0, 1, (-11.9, 0.5, 0.1))])
+def test_kernel_source_matches_oracle_on_cpu(ll_host, n, steps, wind, det, toi_staged, physics):
     """toi_staged = 0: the contact cache's TOI word stays in its column (the 64-lane blocks' layout); in every case the
-    velocity constraints beyond the fourth go through the far-workspace path."""
-    r = subprocess.run([ll_host, str(n), str(steps), str(wind), str(det), str(toi_staged)], capture_output=True, text=True)
+    velocity constraints beyond the fourth go through the far-workspace path.  physics = (gravity, wind_power, turbulence_power) near the
+    ends of the ranges the builder accepts: the sweep loops' early exits (fixed point, cycle, settled velocity) are proofs about the
+    constraint arithmetic and must give the full 180 / 60 iterations' words — which the oracle runs — under any of them."""
+    r = subprocess.run([ll_host, str(n), str(steps), str(wind), str(det), str(toi_staged), *map(str, physics)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     m = re.search(r"mismatches=(\d+) exact_words=(\d+)/(\d+) episodes_done=(\d+) overflow=(\d+)", r.stdout)
     assert m, r.stdout

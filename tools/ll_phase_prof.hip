@@ -61,11 +61,26 @@ int main(int argc, char** argv) {
     std::vector<double> all_tot;
     static double tab_t[6][7], tab_n[6][7];
     double worst_phase[24] = {0}, worst_cnt[24] = {0}, worst_tot = 0, mean_tot = 0; long nwaves = 0;
+    // contact list by kind (MGYM_LL_BUCKET=1, 64-lane blocks): the blocks of the touching end (the first ceil(c1 / 64)) and the others, each by phase
+    static double kind_phase[2][24], kind_cnt[2][24]; double kind_blocks[2] = {0, 0}, kind_tot[2] = {0, 0}, kind_max[2] = {0, 0}, kind_envs[2] = {0, 0};
     for (int t = 0; t < steps; ++t) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blk), zz, sizeof zz)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_blkcnt), zz, sizeof zz));
+        uint32_t wc[2] = {0, 0};
+        CK(hipMemcpy(wc, env.dev.work_count, sizeof wc, hipMemcpyDeviceToHost));   // L_GENERAL (front), L_GENERAL_T (back) of the step about to run
         env.step(act + (uint64_t)(t % 16) * n, nullptr, rew, dn, tr);
         CK(hipStreamSynchronize(env.stream));
         CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_blk), sizeof hb)); CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_blkcnt), sizeof hc));
+        if (env.dev.bucket == 1) {
+            const int heavy_blocks = (int)((wc[1] + 63) / 64);
+            kind_envs[0] += wc[1]; kind_envs[1] += wc[0];
+            for (int b = 0; b < 8192; ++b) {
+                if (!hc[b * 24 + 1]) continue;
+                const int k = b < heavy_blocks ? 0 : 1;
+                double tt = 0;
+                for (int q = 0; q < 24; ++q) { kind_phase[k][q] += (double)hb[b * 24 + q]; kind_cnt[k][q] += (double)hc[b * 24 + q]; tt += (double)hb[b * 24 + q]; }
+                kind_blocks[k] += 1; kind_tot[k] += tt; if (tt > kind_max[k]) kind_max[k] = tt;
+            }
+        }
         int wb = -1; double wt = 0;
         for (int b = 0; b < 8192; ++b) { double tt = 0; for (int q = 0; q < 24; ++q) tt += (double)hb[b * 24 + q]; if (tt > 0) { mean_tot += tt; nwaves++; all_tot.push_back(tt); } if (tt > wt) { wt = tt; wb = b; } }
         for (int b = 0; b < 8192; ++b) {   // contact-role blocks (they pass Collide): time by sub-step passes and by lanes x sub-steps
@@ -86,6 +101,11 @@ int main(int argc, char** argv) {
     double tot = 0; for (int i = 0; i < 24; ++i) tot += (double)p[i];
     printf("wave-cycles by phase over %d steps of %llu envs (general kernel only; shares, not run time):\n", steps, (unsigned long long)n);
     for (int i = 1; i < 24; ++i) if (c[i]) printf("  %-52s %6.2f%%  (%llu stamps, %.0f cyc each)\n", names[i], 100.0 * p[i] / tot, c[i], (double)p[i] / c[i]);
+    for (int k = 0; k < 2; ++k) if (kind_blocks[k] > 0) {
+        printf("%s blocks: %.0f per launch, %.0f envs per launch, mean %.0f cycles per block (slowest %.0f); by phase (share, stamps per block, cycles per stamp):\n", k ? "OTHER (no touching contact)" : "TOUCHING-end",
+               kind_blocks[k] / steps, kind_envs[k] / steps, kind_tot[k] / kind_blocks[k], kind_max[k]);
+        for (int i = 1; i < 24; ++i) if (kind_cnt[k][i] > 0) printf("  %-52s %6.2f%%  %6.2f  %8.0f\n", names[i], 100.0 * kind_phase[k][i] / kind_tot[k], kind_cnt[k][i] / kind_blocks[k], kind_phase[k][i] / kind_cnt[k][i]);
+    }
     printf("slowest wave per launch: %.0f cycles on average (mean wave %.0f); its phases:\n", worst_tot / steps, mean_tot / (nwaves ? nwaves : 1));
     for (int i = 1; i < 24; ++i) if (worst_phase[i] > 0) printf("  %-52s %6.2f%%  (%.1f stamps per launch)\n", names[i], 100.0 * worst_phase[i] / worst_tot, worst_cnt[i] / steps);
     { unsigned long long cyc[2][5][19]; CK(hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cyc), sizeof cyc));
