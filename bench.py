@@ -107,7 +107,7 @@ def launch_mode(requested, family, launch_order="single_launch"):
     """`--launch auto`: hipGraph replay for every family.  CartPole / MountainCar steps are ~10 us (launch-bound); a LunarLander step is
     two launches on the caller's stream (`launch_order` of mgym_get_info = single_launch), which a graph replays exactly as eager
     launches run (profiles/r03_lunarlander/launch_modes.txt).  Only populations that select the multi-stream order (64-lane contact
-    blocks, from 425 984 envs) stay eager: a graph executor serialises its side branches."""
+    blocks, from 376 832 envs) stay eager: a graph executor serialises its side branches."""
     if requested != "auto":
         return requested
     return "eager" if (family == "lunar_lander" and launch_order != "single_launch") else "graph"
@@ -249,7 +249,7 @@ def lunar_roofline(n, step_s, variant=""):
     against the 157.3 TFLOP/s f32 vector peak.  The HBM fraction is given for reference."""
     alg = (107 * 4 * 2 + 46) * n   # state words always touched, R + W, + API traffic
     out = {"bound": "valu", "peak": 157.3, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
-           "kernel": "ll_step_kernel<32> (contact path, free-flight path, reset preparation as block roles of one launch) + ll_epilogue_kernel; from 425 984 envs: ll_contact_kernel<64> beside ll_free_kernel + ll_epilogue_kernel", "avg_step_us": step_s * 1e6,
+           "kernel": "ll_step_kernel<32> (contact path, free-flight path, reset preparation as block roles of one launch) + ll_epilogue_kernel; from 376 832 envs: ll_contact_kernel<64> beside ll_free_kernel + ll_epilogue_kernel", "avg_step_us": step_s * 1e6,
            "hbm_for_reference": {"alg_bytes_per_step": alg, "GBps": alg / step_s / 1e9, "frac": alg / step_s / HBM_PEAK}}
     rec = pmc_record(f"lunar_lander{variant}:{n}")
     if variant:

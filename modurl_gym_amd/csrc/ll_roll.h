@@ -542,8 +542,10 @@ static_assert(ROLL_TO_CONTACT == ROLL_TO_FREE + RQ_CONTACT && ROLL_TO_RESET == R
 // Returns 0 when no slot holds an environment any more, or m != 0: a batch of the contact path has been taken and sits in S.late (m < 0: |m| entries
 // from the light queue, m > 1000: m - 1000 from the sub-step queue, else m from the touching queue; the residents have been flushed; the caller runs
 // the batch — outside this function, so that the slots' registers are dead by then)
-template <int BLK>
-__device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, ContactLds<BLK>& S, uint32_t& finished, RollStat& st) {
+// HELPER (ll_rollout_free_kernel): the wave never takes a batch of the contact path — the function returns 0 only.  LDS: anything with `tab` and `late`.
+struct RollFreeLds { PolyTab tab; uint32_t late[64 * 4]; };
+template <int BLK, bool HELPER = false, class LDS = ContactLds<BLK>>
+__device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, const RollQ& q, const __amdgpu_buffer_rsrc_t rs, LDS& S, uint32_t& finished, RollStat& st) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     const PolyTab& tab = S.tab;
@@ -668,7 +670,7 @@ __device__ __forceinline__ int roll_free_mode(const LLDev& d, const LLIo& io, co
         // ... and the semaphore of a contact-path queue, if a batch's worth was seen waiting (one attempt per step)
         int cclaim_want = 0, cclaim_old = 0;
         // (only a queue that is not AHEAD of the free-flight queue when q.fair: see RC_HEADT)
-        const int cclaim_which = t_avail >= (int)q.toi_min ? RQ_TOI : (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
+        const int cclaim_which = HELPER ? -1 : t_avail >= (int)q.toi_min ? RQ_TOI : (c_avail >= (int)q.heavy_min && (!q.fair || f_avail <= 0 || c_headt <= f_headt)) ? RQ_CONTACT
                                : (l_avail >= (int)q.contact_min && (!q.fair || f_avail <= 0 || l_headt <= f_headt)) ? RQ_LIGHT : -1;
         if (cclaim_which >= 0 && !(q.debug & 4u)) {
             cclaim_want = cclaim_which == RQ_CONTACT ? (c_headt < f_headt ? (int)q.heavy_narrow : (int)q.heavy_max) : BLK;
@@ -909,6 +911,44 @@ ll_rollout_kernel(LLDev d, LLIo io, RollQ q) {
         for (int z = 0; z < RS_COUNT; ++z) mine = lane == z ? st.v[z] : mine;
         if (mine) atomicAdd(q.stat + lane, mine); }
     ll_report(d, not_reset, overflow, finished);
+}
+
+// Free-flight helper waves of the same launch: the waves above are compiled for the contact path (one wave per SIMD, every register) and take their
+// free-flight steps at that occupancy — the sweeps run at the SIMD's issue rate, but everything around them (records in and out, the step's begin and
+// finish, the queues) waits with nothing to switch to.  These waves do nothing but free-flight steps, from the same queue, at several waves per SIMD
+// on the SIMDs the main launch leaves free.  They are an accelerator, never a dependency: the main waves serve every queue, so the launch completes
+// whether or not a single helper wave ever becomes resident; a helper exits when every environment has finished (or the launch was aborted).
+#ifndef LL_ROLL_HELPER_OCC
+#define LL_ROLL_HELPER_OCC 2
+#endif
+template <int BLK>
+__global__ void __launch_bounds__(64, LL_ROLL_HELPER_OCC)
+ll_rollout_free_kernel(LLDev d, LLIo io, RollQ q) {
+    __shared__ RollFreeLds S;
+    const int lane = threadIdx.x & 63;
+    uint32_t finished = 0u;
+    RollStat st = {};
+    stage_tab(S.tab, LLK(d));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.st, 0, 0xffffffff, 0x00020000);
+    const long long t_begin = wall_clock64();
+    for (;;) {
+        uint32_t seen = 0u;
+        if (lane < RC_HEADT) seen = RQ_LOAD(rq_ctl(q, lane));
+        const int avail = __builtin_amdgcn_readlane((int)seen, RC_AVAIL + RQ_FREE);
+        const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)seen, RC_LIVE);
+        if (live == 0u || rq_aborted(q)) break;
+        if (wall_clock64() - t_begin > 4 * kRollTimeoutTicks) break;   // (never the one to abort: the main waves finish the launch without it)
+        if (avail >= (int)q.helper_min) {
+            roll_free_mode<BLK, true, RollFreeLds>(d, io, q, rs, S, finished, st);
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+    if (lane < RS_COUNT && q.stat) { unsigned long long mine = 0ull;   // (its free-flight steps are counted, its time is not: RS_N_WAVES stays the main launch's)
+#pragma unroll
+        for (int z = 0; z < RS_COUNT; ++z) mine = lane == z ? st.v[z] : mine;
+        if (mine && (lane == RS_N_FREE_STEPS || lane == RS_N_FREE_LANE_STEPS)) atomicAdd(q.stat + RS_N_HELPER_STEPS + (lane == RS_N_FREE_LANE_STEPS ? 1 : 0), mine); }
+    ll_flush_done(d, finished);
 }
 
 // slot k of every ring starts with sequence k; control words zero

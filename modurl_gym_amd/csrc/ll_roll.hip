@@ -9,9 +9,12 @@ int ll_rollout_blocks_per_cu(int* per_cu) {
     return MGYM_OK;
 }
 void ll_rollout_ring_init(hipStream_t s, const RollQ& q) { hipLaunchKernelGGL(ll_rollout_ring_init_kernel, dim3(256), dim3(256), 0, s, q); }
-void ll_rollout_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q, uint32_t n) {
-    hipLaunchKernelGGL(ll_rollout_begin_kernel, dim3(1), dim3(64), 0, s, q, n);
+void ll_rollout_begin(hipStream_t s, const RollQ& q, uint32_t n) { hipLaunchKernelGGL(ll_rollout_begin_kernel, dim3(1), dim3(64), 0, s, q, n); }
+void ll_rollout_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q) {
     hipLaunchKernelGGL(ll_rollout_kernel<32>, dim3(grid), dim3(64), 0, s, d, io, q);
+}
+void ll_rollout_helper_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q) {
+    hipLaunchKernelGGL(ll_rollout_free_kernel<32>, dim3(grid), dim3(64), 0, s, d, io, q);
 }
 
 }  // namespace mgym

@@ -28,7 +28,7 @@ enum { RQ_FREE = 0, RQ_CONTACT = 1, RQ_RESET = 2, RQ_LIGHT = 3, RQ_TOI = 4, RQ_C
 enum { RC_AVAIL = 0 /* + queue */, RC_LIVE = 5, RC_HEADT = 6 /* + queue */, RC_HEAD = 11 /* + queue */, RC_TAIL = 16 /* + queue */, RC_CHUNK = 21, RC_ABORT = 22, RC_WORDS = 24 };
 // per-launch work statistics (ticks of the 100 MHz wall clock summed over the waves; read by MGYM_LL_ROLL_STATS=1 / tools): cheap enough to stay in
 enum { RS_T_TOTAL = 0, RS_T_SEED, RS_T_CONTACT, RS_N_CONTACT_BATCHES, RS_N_CONTACT_LANES, RS_T_RESET, RS_N_RESET_LANES, RS_T_FREE, RS_N_FREE_STEPS, RS_N_FREE_LANE_STEPS,
-       RS_N_REFILLS, RS_T_IDLE, RS_N_SWITCHES, RS_T_FREE_QUEUE, RS_N_WAVES, RS_T_FREE_BEGIN, RS_T_FREE_SWEEPS, RS_T_FREE_FINISH, RS_T_FREE_ISSUE, RS_N_MAIN, RS_T_LIGHT, RS_N_LIGHT_BATCHES, RS_N_LIGHT_LANES, RS_N_ROTATIONS, RS_T_TOI, RS_N_TOI_BATCHES, RS_N_TOI_LANES, RS_COUNT = 28 };
+       RS_N_REFILLS, RS_T_IDLE, RS_N_SWITCHES, RS_T_FREE_QUEUE, RS_N_WAVES, RS_T_FREE_BEGIN, RS_T_FREE_SWEEPS, RS_T_FREE_FINISH, RS_T_FREE_ISSUE, RS_N_MAIN, RS_T_LIGHT, RS_N_LIGHT_BATCHES, RS_N_LIGHT_LANES, RS_N_ROTATIONS, RS_T_TOI, RS_N_TOI_BATCHES, RS_N_TOI_LANES, RS_N_HELPER_STEPS, RS_N_HELPER_LANE_STEPS, RS_COUNT = 30 };
 struct RollStat { unsigned long long v[RS_COUNT]; };
 struct RollQ {
     unsigned long long* ring;   // [RQ_COUNT][cap] slots {sequence << 32 | entry}; slot k starts with sequence k
@@ -49,6 +49,7 @@ struct RollQ {
                                 // environment are the launch's longest chain, and a batch is as slow as it is wide (more sub-step passes, slower lanes)
     uint32_t reset_min;         // ... and a reset batch only when at least this many finished environments wait
     uint32_t free_min;          // ... and goes into free-flight mode only when at least this many entries wait
+    uint32_t helper_min;        // a free-flight helper wave (ll_rollout_free_kernel) boards when at least this many entries wait
     uint32_t refill_min;        // a resident wave refills its vacant lanes only when at least this many are vacant
     uint32_t residency;         // ... and, while a wave's worth of free-flight entries waits, trades ALL its environments for waiting ones after this many
                                 // steps: the population then advances evenly (entries come out of the ring lowest step index first), and the

@@ -1280,6 +1280,41 @@ LLD void toi_evaluate(World& wo, const PolyTab& tab, int slot) {
     ct_set_key(wo.cs, slot, key | CK_TOIFLAG);
 }
 
+// The same evaluation as a TASK RECORD that any lane can run — for blocks whose World records are private to their lanes (64-lane blocks)
+// and which still deal the evaluations of a pass out over the wave: the owner writes the operands (the body's sweep, the edge, the polygon:
+// 14 words, column `t` of a [16][stride] table in LDS), some lane computes, the owner applies the result to its contact.  Same operations on the
+// same operands as toi_evaluate.
+constexpr int kToiTaskWords = 16;
+LLD void toi_task_write(const World& wo, int slot, LL_LDS float* rec, int stride) {
+    const uint32_t key = ct_key(wo.cs, slot);
+    const int body = ck_body(key);
+    const Sweep& sw = wo.b[body].sw;
+    V2 v1, v2;
+    edge_verts(wo, ck_edge(key), v1, v2);
+    const bool skip = LL_WHATIF(wo, WI_NO_TOI_EVAL) || (LL_WHATIF(wo, WI_SUB_NO_REEVAL) && wo.gA > 0.0f);
+    rec[0 * stride] = sw.localCenter.x; rec[1 * stride] = sw.localCenter.y; rec[2 * stride] = sw.c0.x; rec[3 * stride] = sw.c0.y;
+    rec[4 * stride] = sw.c.x; rec[5 * stride] = sw.c.y; rec[6 * stride] = sw.a0; rec[7 * stride] = sw.a; rec[8 * stride] = sw.alpha0;
+    rec[9 * stride] = v1.x; rec[10 * stride] = v1.y; rec[11 * stride] = v2.x; rec[12 * stride] = v2.y;
+    rec[13 * stride] = as_f32(skip ? 0xffffffffu : (uint32_t)poly_of(body));
+}
+LLD void toi_task_run(LL_LDS float* rec, int stride, const PolyTab& tab) {
+    Sweep sw;
+    sw.localCenter = mk(rec[0 * stride], rec[1 * stride]); sw.c0 = mk(rec[2 * stride], rec[3 * stride]); sw.c = mk(rec[4 * stride], rec[5 * stride]);
+    sw.a0 = rec[6 * stride]; sw.a = rec[7 * stride]; sw.alpha0 = rec[8 * stride];
+    V2 ev[2];
+    ev[0] = mk(rec[9 * stride], rec[10 * stride]); ev[1] = mk(rec[11 * stride], rec[12 * stride]);
+    const uint32_t pi = as_u32(rec[13 * stride]);
+    float beta;
+    LL_STAMP(8);
+    const int state = pi == 0xffffffffu ? TOI_SEPARATED : time_of_impact(ev, tab, (int)pi, sw, beta);
+    LL_STAMP(9);
+    rec[14 * stride] = state == TOI_TOUCHING ? fmin2(sw.alpha0 + (1.0f - sw.alpha0) * beta, 1.0f) : 1.0f;
+}
+LLD void toi_task_apply(World& wo, int slot, const LL_LDS float* rec, int stride) {
+    ct_set_toi(wo.cs, slot, rec[14 * stride]);
+    ct_set_key(wo.cs, slot, ct_key(wo.cs, slot) | CK_TOIFLAG);
+}
+
 enum { TOI_DONE = 0, TOI_AGAIN = 1, TOI_OUT_OF_BUDGET = 2 };
 LLD int toi_advance(World& w, const PolyTab& tab, const LLConst& k, const CSolverMem& mem, float dt, ToiLoop& L, int& budget) {
     uint8_t* const order = (uint8_t*)w.t->idx[0];

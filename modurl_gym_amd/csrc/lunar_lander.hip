@@ -13,7 +13,7 @@
 // Bound: f32 VALU issue / dependent-chain latency (180 Gauss-Seidel sweeps over 2 joints + contacts
 // per step, ~3-5e4 flops per ~1 KB of state traffic) — NOT HBM; bench.py reports it that way.
 //
-// One mgym_step (LunarLanderEnv::step).  Up to 425 984 envs per handle — TWO launches on the caller's stream:
+// One mgym_step (LunarLanderEnv::step).  Below 376 832 envs per handle — TWO launches on the caller's stream:
 //   ll_step_kernel<32>          the whole step, block roles by index: contact path over the list the previous call's epilogue built
 //                               (Collide, island solve, SolveTOI with the wave's time-of-impact evaluations dealt out over all 64
 //                               lanes), free-flight path over everyone else (register-only; an env that ends its step with a contact
@@ -357,6 +357,35 @@ __device__ __forceinline__ void ll_contact_body(const LLDev& d, const LLIo& io, 
             } else if (stepping) {
                 step_complete = solve_toi_part(w, tab, LLK(d), mem, kStepDt, true, toi_budget);
             }
+        } else if (toi_budget < 0) {
+            // 64-lane blocks: every lane holds an env and the World records are private (registers / scratch), but a wave's evaluations are as
+            // unevenly spread as in the small blocks (most lanes none, a few lanes up to nine per pass: the wave used to take ~12 evaluation slots
+            // per step for ~2 evaluations per env).  They are dealt out as TASK RECORDS (ll_world.h toi_task_*): the owners write the operands into
+            // the block's constraint columns — which nothing uses between two time-of-impact islands —, the wave's lanes take one record each,
+            // the owners apply the results.
+            constexpr int kTaskCap = (int)(sizeof(S.vc) / (kToiTaskWords * sizeof(float)));
+            LL_LDS float* const trec = (LL_LDS float*)S.vc;
+            ToiLoop L;
+            bool running = stepping && toi_begin(w, L, true);
+            int budget = -1;
+            while (__any(running)) {   // wave-uniform (a 64-lane block is one wave)
+                const int n_need = running ? toi_list(w, L) : 0;
+                int incl = n_need;
+                for (int dlt = 1; dlt < 64; dlt <<= 1) { const int v = __shfl_up(incl, dlt); if ((int)threadIdx.x >= dlt) incl += v; }
+                const int n_tasks = __shfl(incl, 63);
+                const int offs = incl - n_need;
+                const uint8_t* const need = (const uint8_t*)((LL_LDS WorldTmp*)S.tmp + own)->idx[1];
+                for (int c0 = 0; c0 < n_tasks; c0 += kTaskCap) {   // (one round unless the wave holds more than kTaskCap evaluations)
+                    for (int j = 0; j < n_need; ++j) { const int t = offs + j - c0; if (t >= 0 && t < kTaskCap) toi_task_write(w, need[j], trec + t, kTaskCap); }
+                    __syncthreads();
+                    const int n_here = n_tasks - c0 < kTaskCap ? n_tasks - c0 : kTaskCap;
+                    for (int t = (int)threadIdx.x; t < n_here; t += kThreads) toi_task_run(trec + t, kTaskCap, tab);
+                    __syncthreads();
+                    for (int j = 0; j < n_need; ++j) { const int t = offs + j - c0; if (t >= 0 && t < kTaskCap) toi_task_apply(w, need[j], trec + t, kTaskCap); }
+                    __syncthreads();
+                }
+                if (running) running = toi_advance(w, tab, LLK(d), mem, kStepDt, L, budget) == TOI_AGAIN;
+            }
         } else {
             if (stepping) step_complete = solve_toi_part(w, tab, LLK(d), mem, kStepDt, true, toi_budget);
         }
@@ -693,7 +722,9 @@ ll_step_kernel(LLDev d, LLDev sh, LLIo io, unsigned g_contact, unsigned g_free) 
 // mgym_rollout: K steps in one persistent launch, environments advancing independently — ll_roll.h, compiled in ll_roll.hip
 int ll_rollout_blocks_per_cu(int* per_cu);
 void ll_rollout_ring_init(hipStream_t s, const RollQ& q);
-void ll_rollout_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q, uint32_t n);
+void ll_rollout_begin(hipStream_t s, const RollQ& q, uint32_t n);
+void ll_rollout_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q);
+void ll_rollout_helper_launch(hipStream_t s, unsigned grid, const LLDev& d, const LLIo& io, const RollQ& q);
 
 // Staged resets.  The state an env has after reset() — scene, implicit step(0), observation — is a pure function of
 // (seed, env id, episode counter), so it does not have to be computed when the episode ends, on the critical path of
@@ -957,8 +988,12 @@ struct LunarLanderEnv final : Env {
     int free_occ = getenv("MGYM_LL_FREE_OCC") ? atoi(getenv("MGYM_LL_FREE_OCC")) : 2;  // waves/SIMD the free kernel is compiled for
 #endif
     int vc_near_limit = kVcNearLds;     // velocity constraints per lane the contact kernel keeps in LDS (init(); MGYM_LL_VC_NEAR lowers it: test knob)
-    // mgym_rollout as ONE persistent launch (ll_roll.h); MGYM_LL_ROLLOUT=0: K x step()
-    int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : 1;
+    // mgym_rollout as ONE persistent launch (ll_roll.h); MGYM_LL_ROLLOUT=0: K x step(), 1: always, unset: below 491 520 envs — above, K steps of the
+    // multi-stream order are as fast or faster (524 288 envs, K = 64: 1.34 ms per step against 1.30; 1 Mi: 2.63 against 2.15: both bound by SIMD
+    // occupancy there, and the step's free-flight kernel runs at two waves per SIMD; profiles/r04_lunarlander/rollout_by_population.txt)
+    int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : -1;
+    int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : 1;   // free-flight helper waves beside the main launch (init)
+    unsigned roll_helper_grid = 0;
     int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : 8;   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
     void* roll_ring = nullptr;
     void* roll_ctl = nullptr;
@@ -1001,7 +1036,9 @@ struct LunarLanderEnv final : Env {
         // at every size once the blocks are chosen this way.
         // (round 3, single-launch step with 32-lane blocks against the multi-stream order with 64-lane blocks: 393 216 envs 1.54 / 1.57 ms,
         // 524 288: 2.04 / 1.68, 1 Mi: 3.81 / 2.86, 2 Mi: 7.38 / 6.11 — profiles/r03_lunarlander/population_block_matrix.txt)
-        if (gen_block == 0) gen_block = n >= 425984 ? 64 : 32;
+        // (round 4, after the 64-lane blocks began to deal their time-of-impact evaluations out over the wave: 360 448 envs 1.26 / 1.29, 393 216: 1.39 / 1.30,
+        // 425 984: 1.46 / 1.29 — profiles/r04_lunarlander/block_switch_by_population.txt)
+        if (gen_block == 0) gen_block = n >= 376832 ? 64 : 32;
 #ifndef LL_DIAG
         if (gen_block != 32 && gen_block != 64) { set_last_error("MGYM_LL_GENERAL_BLOCK: 32 or 64 (other contact-block sizes exist in -DLL_DIAG builds only)"); return MGYM_ERR_BAD_CONFIG; }
 #endif
@@ -1086,6 +1123,7 @@ struct LunarLanderEnv final : Env {
         }
         // mgym_rollout's persistent launch: rings of >= n slots per queue, one wave per SIMD as many as are resident at once, a slice of
         // far-constraint workspace per wave.  (Records are addressed by 32-bit byte offsets there: n_pad x 1152 B < 4 GiB.)
+        if (roll_enabled < 0) roll_enabled = n < 491520 ? 1 : 0;
         roll_enabled = roll_enabled && !general_only && n > 0 && n <= kRollEnvMask && (uint64_t)n_pad * kRec * 4ull < 0xffffffffull;
         if (roll_enabled) {
             uint64_t cap = 64;
@@ -1126,6 +1164,20 @@ struct LunarLanderEnv final : Env {
             if (ll_rollout_blocks_per_cu(&per_cu) != MGYM_OK) return MGYM_ERR_HIP;
             if (per_cu < 1) per_cu = 1;
             uint64_t g = (uint64_t)per_cu * (uint64_t)prop.multiProcessorCount;
+            // Free-flight helper waves (ll_rollout_free_kernel) beside the main launch: the main waves fill a SIMD each (256 + 256 registers), so they
+            // get three SIMDs of every CU and the helpers — two waves per SIMD — the fourth.  262 144 envs, ms per step-equivalent without | with
+            // (profiles/r04_lunarlander/rollout_helper_waves.txt): K = 8 0.91 | 0.87, K = 16 0.81 | 0.77, K = 64 0.71 | 0.68; the helpers then take 86 % of the
+            // free-flight steps at 46 us of SIMD time per 64 env-steps against 79 in a main wave, and the 768 main waves are busy with the contact
+            // path throughout (35 of 45 ms).  Two SIMDs per CU for the helpers: 1.05 (the contact path is the larger share); four main waves per CU:
+            // no helper ever becomes resident and the launch runs as before (0.71) — the helpers are an accelerator, never a dependency.
+            roll_helper_grid = 0;
+            if (roll_helper && per_cu >= 4) {
+                const unsigned main_per_cu = LL_TUNE("MGYM_LL_ROLL_MAIN_PER_CU", 3u), help_per_cu = LL_TUNE("MGYM_LL_ROLL_HELPER_PER_CU", 2u);
+                if ((int)main_per_cu < per_cu && main_per_cu >= 1) g = (uint64_t)main_per_cu * (uint64_t)prop.multiProcessorCount;
+                roll_helper_grid = help_per_cu * (unsigned)prop.multiProcessorCount;
+                if ((uint64_t)roll_helper_grid * 64 > n) roll_helper_grid = (unsigned)(n / 64);
+            }
+            rq.helper_min = LL_TUNE("MGYM_LL_ROLL_HELPER_MIN", 256u);
             if (LL_TUNE("MGYM_LL_ROLL_GRID", 0u)) g = (uint64_t)LL_TUNE("MGYM_LL_ROLL_GRID", 0u);
             const uint64_t need = (n + 31) / 32;   // more waves than 32-lane batches can never be busy
             if (g > need) g = need;
@@ -1153,7 +1205,15 @@ struct LunarLanderEnv final : Env {
                     done ? done + (size_t)k0 * n : nullptr, trunc ? trunc + (size_t)k0 * n : nullptr};
             RollQ q = rq; q.K = (uint32_t)kc;
             if (roll_trace) MGYM_HIP(hipMemsetAsync(roll_trace, 0, (size_t)roll_grid * kRollTraceLen * sizeof(unsigned long long), stream));
-            ll_rollout_launch(stream, roll_grid, rd, io, q, (uint32_t)n);
+            ll_rollout_begin(stream, q, (uint32_t)n);
+            if (roll_helper_grid) MGYM_HIP(hipEventRecord(ev_fork, stream));
+            ll_rollout_launch(stream, roll_grid, rd, io, q);
+            if (roll_helper_grid) {   // the helper waves beside it, on the helper stream (fork / join by events: stream-ordered for the caller, capturable)
+                MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+                ll_rollout_helper_launch(aux, roll_helper_grid, rd, io, q);
+                MGYM_HIP(hipEventRecord(ev_join, aux));
+                MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+            }
         }
         if (roll_trace) {
             std::vector<unsigned long long> h((size_t)roll_grid * kRollTraceLen);
@@ -1177,6 +1237,8 @@ struct LunarLanderEnv final : Env {
                     h[RS_T_FREE] * us / w, h[RS_N_FREE_STEPS] / w, h[RS_N_FREE_STEPS] ? (double)h[RS_N_FREE_LANE_STEPS] / h[RS_N_FREE_STEPS] : 0.0, per(RS_T_FREE, RS_N_FREE_STEPS),
                     per(RS_T_FREE_BEGIN, RS_N_FREE_STEPS), per(RS_T_FREE_ISSUE, RS_N_FREE_STEPS), per(RS_T_FREE_SWEEPS, RS_N_FREE_STEPS), per(RS_T_FREE_FINISH, RS_N_FREE_STEPS), per(RS_T_FREE_QUEUE, RS_N_FREE_STEPS),
                     h[RS_N_REFILLS] / w, h[RS_N_SWITCHES] / w, h[RS_N_ROTATIONS] / w, h[RS_T_IDLE] * us / w, h[RS_N_MAIN] / w);
+            if (roll_helper_grid) fprintf(stderr, "   free-flight helper waves (%u blocks): %.0f wave-steps of %.1f lanes (main waves: %.0f wave-steps)\n", roll_helper_grid, (double)h[RS_N_HELPER_STEPS],
+                                          h[RS_N_HELPER_STEPS] ? (double)h[RS_N_HELPER_LANE_STEPS] / h[RS_N_HELPER_STEPS] : 0.0, (double)h[RS_N_FREE_STEPS]);
         }
         if (staged) direct_possible = true;   // episodes that ended inside the launch were reset there: their prepared successors no longer fit
         if (fused_tail) { st = rebuild_list(); if (st != MGYM_OK) return st; }
@@ -1476,8 +1538,8 @@ struct LunarLanderEnv final : Env {
         out += "contact_block=" + std::to_string(gen_block) + "\nlaunch_order=" + (single_launch ? "single_launch" : overlap ? "overlapped" : "sequential") +
                "\nstaged_resets=" + (staged ? "1" : "0") + "\ncontact_list_by_kind=" + std::to_string(dev.bucket) + "\ncontact_blocks_target=" + std::to_string(single_launch ? dev.contact_blocks : 0) +
                "\nknobs=MGYM_LL_GENERAL_BLOCK(32|64) MGYM_LL_SINGLE_LAUNCH MGYM_LL_STAGED_RESET MGYM_LL_STAGED_IN_GRAPH MGYM_LL_CONTACT_BLOCKS MGYM_LL_VC_NEAR MGYM_LL_RESUME MGYM_LL_GENERAL_ONLY "
-               "MGYM_LL_AUX_PRIO MGYM_LL_BUCKET MGYM_LL_ROLLOUT MGYM_LL_ROLLOUT_MIN_K MGYM_LL_ROLL_STATS MGYM_LL_ROLL_TRACE" +
-               "\nrollout=" + (roll_enabled ? "persistent_launch" : "k_steps") + "\nrollout_min_k=" + std::to_string(roll_min_k) + "\nrollout_waves=" + std::to_string(roll_grid) + "\n";
+               "MGYM_LL_AUX_PRIO MGYM_LL_BUCKET MGYM_LL_ROLLOUT MGYM_LL_ROLLOUT_MIN_K MGYM_LL_ROLL_HELPER MGYM_LL_ROLL_STATS MGYM_LL_ROLL_TRACE" +
+               "\nrollout=" + (roll_enabled ? "persistent_launch" : "k_steps") + "\nrollout_min_k=" + std::to_string(roll_min_k) + "\nrollout_waves=" + std::to_string(roll_grid) + "\nrollout_helper_blocks=" + std::to_string(roll_helper_grid) + "\n";
         if (capturing()) { set_last_error("mgym_get_info: the stream is being captured (the call launches probe kernels and synchronises)"); return MGYM_ERR_BAD_ARG; }
         hipStream_t ss[3] = {stream, aux, aux2};
         const int ns = aux2 ? 3 : 2;

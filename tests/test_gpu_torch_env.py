@@ -124,7 +124,7 @@ def test_argument_checks():
 
 
 def test_lunar_lander_steps_captured_by_torch_cuda_graph_at_the_multi_stream_size(monkeypatch):
-    """A capture the engine did not begin itself: `torch.cuda.graph` around `TorchVecEnv.step` at 425 984 envs, the smallest population that
+    """A capture the engine did not begin itself: `torch.cuda.graph` around `TorchVecEnv.step` at 425 984 envs, a population that
     runs the multi-stream order (64-lane contact kernel beside the free-flight kernel, helper streams forked from and joined to the capturing
     stream by events, staged resets prepared beside later steps).  Replays interleaved with eager steps must give the words of a plain handle
     that computes every reset when the episode ends (MGYM_LL_STAGED_RESET=0) — the pending reset preparations are handed over between eager

@@ -2,9 +2,10 @@
 # Runs ON the GPU box: kernel trace of a few LunarLander steps in the overlapped launch order; prints the timeline of
 # one step (start / end of every kernel relative to the step's first kernel) — do the two streams really run side by side?
 cd /tmp && export TMPDIR=/tmp
-export MGYM_LL_OVERLAP=${1:-1} MGYM_LL_GENERAL_BLOCK=${2:-32}
+# usage: [ENVS=1048576] [MGYM_LL_BUCKET=..] tools/ll_overlap_trace.sh   (the engine's knobs pass through the environment)
+ENVS=${ENVS:-262144}
 rm -rf /tmp/llov
-rocprofv3 --kernel-trace --output-format csv -d /tmp/llov -- python3 $GRAFT_REPO_ROOT/bench.py --workload lunar_lander --steps 8 --warmup 400 --launch eager --no-cpu-baseline --no-extra > /tmp/llov.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/llov -- python3 $GRAFT_REPO_ROOT/bench.py --workload lunar_lander --envs $ENVS --steps 8 --warmup 400 --launch eager --no-cpu-baseline --no-extra > /tmp/llov.log 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []

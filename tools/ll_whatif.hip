@@ -13,7 +13,8 @@
 #include "../modurl_gym_amd/csrc/lunar_lander.hip"
 // (the persistent rollout launch lives in ll_roll.hip; these stand-alone measurement binaries never call it)
 namespace mgym { int ll_rollout_blocks_per_cu(int* per_cu) { *per_cu = 1; return 0; } void ll_rollout_ring_init(hipStream_t, const RollQ&) {}
-void ll_rollout_launch(hipStream_t, unsigned, const LLDev&, const LLIo&, const RollQ&, uint32_t) {} }
+void ll_rollout_begin(hipStream_t, const RollQ&, uint32_t) {} void ll_rollout_launch(hipStream_t, unsigned, const LLDev&, const LLIo&, const RollQ&) {}
+void ll_rollout_helper_launch(hipStream_t, unsigned, const LLDev&, const LLIo&, const RollQ&) {} }
 
 #include <stdio.h>
 #include <vector>

@@ -20,7 +20,7 @@ for K in 8 16 64; do
   python tools/ll_roll_trace.py $O/trace_K$K.bin 250 > $O/rollout_timeline_K$K.txt 2>&1 && rm -f $O/trace_K$K.bin || exit 1
 done &&
 for N in 65536 131072 262144 524288 1048576; do
-  python tools/ll_roll_check.py time $N 16 10 >> $O/rollout_population.txt 2>&1 &&
-  python tools/ll_roll_check.py time $N 64 4 >> $O/rollout_population.txt 2>&1 || exit 1
+  MGYM_LL_ROLLOUT=1 python tools/ll_roll_check.py time $N 16 10 >> $O/rollout_population.txt 2>&1 &&
+  MGYM_LL_ROLLOUT=1 python tools/ll_roll_check.py time $N 64 4 >> $O/rollout_population.txt 2>&1 || exit 1
 done
 echo "round_records rc=$?"
