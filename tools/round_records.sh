@@ -22,5 +22,8 @@ done &&
 for N in 65536 131072 262144 524288 1048576; do
   MGYM_LL_ROLLOUT=1 python tools/ll_roll_check.py time $N 16 10 >> $O/rollout_population.txt 2>&1 &&
   MGYM_LL_ROLLOUT=1 python tools/ll_roll_check.py time $N 64 4 >> $O/rollout_population.txt 2>&1 || exit 1
-done
+done &&
+python tools/ll_roll_check.py check 65536 1024 64 > $O/soak_rollout.txt 2>&1 &&
+python tools/ll_roll_check.py check 16384 1536 16 >> $O/soak_rollout.txt 2>&1 &&
+python tools/ll_roll_check.py check 8192 1200 8 1 0 >> $O/soak_rollout.txt 2>&1
 echo "round_records rc=$?"
