@@ -181,6 +181,9 @@ int mgym_observation_aos(mgym_env *env, float *out_aos);
 
 /* Test seam / checkpoint ≙ Testable::set_state (src/testing.rs:15-18).  blob = [state_cols][n_envs]
  * 4-byte words (integer columns as bit patterns); column meaning per kind in DESIGN.md.
+ * LunarLander: the blob carries the bodies, legs, counters and the episode number, not the terrain — as in the reference,
+ * where set_state moves the lander of an existing world (lunar_lander.rs Testable impl) — so the handle must have been reset
+ * before a state is imported; an environment without a world keeps none and mgym_step reports MGYM_ERR_NOT_RESET for it.
  *
  * LIMITS of the CartPole counters (the engine keeps steps_since_reset, steps_beyond_terminated and the per-env
  * episode number in ONE 32-bit word per env, cartpole_step.h):
