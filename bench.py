@@ -253,7 +253,8 @@ def lunar_roofline(n, step_s, variant=""):
            "hbm_for_reference": {"alg_bytes_per_step": alg, "GBps": alg / step_s / 1e9, "frac": alg / step_s / HBM_PEAK}}
     rec = pmc_record(f"lunar_lander{variant}:{n}")
     if variant:
-        out["kernel"] = "ll_rollout_kernel<32> (one persistent launch per K steps: free-flight residents, contact / light-contact / reset batches through device queues)"
+        out["kernel"] = ("ll_rollout_kernel<32> (one persistent launch per K steps: free-flight residents, touching / light-contact / sub-step / reset batches through device queues) "
+                         "+ ll_rollout_free_kernel<32> (free-flight helper waves beside it; the counter passes serialise kernels, so there the main waves did the helpers' steps too: same work)")
     if rec:
         out["achieved"] = rec["f32_flop_per_step_active_lanes"] / step_s / 1e12
         out["frac"] = out["achieved"] / 157.3
