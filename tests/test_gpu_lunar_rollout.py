@@ -102,3 +102,41 @@ def test_rollout_without_outputs_and_short_rollouts_fall_back():
         e = twin.step(short[k])
         assert all(np.array_equal(words(x[k]), words(y)) for x, y in zip(g, e))
     env.sync(), twin.sync()
+
+
+def test_rollout_captured_into_a_graph_replays_like_eager_rollouts():
+    """mgym_graph_begin / _end around mgym_rollout: the persistent launch and its free-flight helper waves (helper stream, fork / join by events
+    recorded inside the capture) become one hipGraph; replays — state is read when the graph runs — must give the words of eager rollouts from the
+    same state.  Actions and outputs are the captured device buffers, rewritten between replays."""
+    n, K = 16384, 8
+    kw = dict(seed=41, enable_wind=True, auto_reset=True)
+    g_env, e_env = mg.VecEnv(mg.LUNARLANDER, n, **kw), mg.VecEnv(mg.LUNARLANDER, n, **kw)
+    assert int(g_env.info()["rollout_helper_blocks"]) > 0
+    assert np.array_equal(g_env.reset(), e_env.reset())
+    rng = np.random.default_rng(8)
+    for t in range(64):   # until contacts, crashes and resets are frequent
+        a = rng.integers(0, 4, n).astype(np.uint32)
+        g_env.step(a), e_env.step(a)
+    d_act = mg.DeviceArray.from_numpy(np.zeros((K, n), np.uint32))
+    d_obs, d_rew = mg.DeviceArray((K, 8, n), np.float32), mg.DeviceArray((K, n), np.float32)
+    d_done, d_trunc = mg.DeviceArray((K, n), np.uint8), mg.DeviceArray((K, n), np.uint8)
+    graph = g_env.graph_capture(lambda: g_env.rollout_device(d_act, K, d_obs, d_rew, d_done, d_trunc))
+    assert np.array_equal(words(g_env.get_state()), words(e_env.get_state()))   # capturing advanced nothing
+    finished = 0
+    for rep in range(4):
+        acts = rng.integers(0, 4, (K, n)).astype(np.uint32)
+        d_act.copy_from(acts)
+        g_env.graph_launch(graph)
+        g_env.sync()
+        exp = e_env.rollout(acts)
+        for g, e, nm in zip((d_obs.numpy(), d_rew.numpy(), d_done.numpy(), d_trunc.numpy()), exp, ("obs", "reward", "done", "truncated")):
+            assert np.array_equal(words(g), words(e)), f"replay {rep}: {nm}"
+        finished += int(exp[2].sum())
+        if rep == 1:   # eager steps between replays
+            a = rng.integers(0, 4, n).astype(np.uint32)
+            for g, e in zip(g_env.step(a), e_env.step(a)):
+                assert np.array_equal(words(g), words(e))
+    assert finished > 500
+    assert np.array_equal(words(g_env.get_state()), words(e_env.get_state()))
+    g_env.graph_destroy(graph)
+    g_env.close(), e_env.close()
