@@ -700,6 +700,19 @@ def main():
         extra["mountain_car_rollout_K16"] = {"env_steps_per_s": st.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps, "n_envs": st.n, "steps": ksteps,
                                              "alg_bytes_per_env_step": 10 + 16 / RING,
                                              "note": "mgym_rollout: K=16 steps per launch (action 4 R + reward 4 W + flags 2 W per step, state 8 R + 8 W per launch), bit-identical to 16 mgym_step calls"}
+        # ... and under the in-kernel linear policy (mgym_rollout_linear, Discrete(3): the index of the largest of three scores; here: push with the velocity)
+        pol = [0.0, -30.0, 0.0, 0.0, 0.0, 1e-4, 0.0, 30.0, 0.0]
+        for _ in range(4):
+            st.env.rollout_linear_device(pol, RING, None, None, rw, dn, tr)
+        st.env.sync()
+        st.env.timer_start()
+        for _ in range(reps):
+            st.env.rollout_linear_device(pol, RING, None, None, rw, dn, tr)
+        ms = st.env.timer_stop()
+        st.env.sync()
+        extra["mountain_car_rollout_linear_policy_K16"] = {"env_steps_per_s": st.n * ksteps / (ms * 1e-3), "us_per_step": ms * 1e3 / ksteps, "n_envs": st.n, "steps": ksteps,
+                                                           "note": "mgym_rollout_linear: a = argmax_j (w_j . obs + b_j) evaluated in the rollout kernel (no action table); equal to a stepping loop "
+                                                                   "with the same weights and to the oracle (tests/test_gpu_classic.py)"}
         st.close()
         # the step either side of the path: a torch policy produces the actions on the same
         # stream, the engine steps, the next observation feeds the policy — no host synchronisation in the loop

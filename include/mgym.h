@@ -160,8 +160,10 @@ int mgym_rollout_uniform(mgym_env *env, uint64_t policy_seed, int32_t K, void *a
  * observation, produces the action): at every step env i takes action 1 if ((w[0]*x + w[1]*x_dot) + w[2]*theta) + w[3]*theta_dot + b > 0 (f32, evaluated in
  * exactly that order, nothing fused), else 0, on the observation it holds BEFORE the step — the loop a trainer's rollout collector runs
  * (`let a = policy(&obs); let info = env.step(a)`, cartpole.rs:251-348) without leaving the GPU's registers.  `policy` is a HOST pointer to obs_dim weights
- * followed by the bias (5 floats, read during the call).  actions_out ([K][n_envs] uint32, may be NULL) receives the actions taken.  CartPole only; n_envs a
- * multiple of 4. */
+ * followed by the bias (5 floats, read during the call).  actions_out ([K][n_envs] uint32, may be NULL) receives the actions taken.
+ * MountainCar (Discrete(3), mountain_car.rs:293-330): `policy` = three rows of (w_position, w_velocity, bias), 9 floats; the action is the index of the largest
+ * score s_j = (w_j0 * position + w_j1 * velocity) + b_j, the first of equal ones.  MountainCarContinuous: one row, 3 floats; the score itself is the force
+ * (actions_out then holds f32 words).  n_envs a multiple of 4.  LunarLander: MGYM_ERR_BAD_ARG (its rollout is a persistent launch of its own, ll_roll.h). */
 int mgym_rollout_linear(mgym_env *env, const float *policy, int32_t K, void *actions_out, float *obs_out,
                         float *reward_out, uint8_t *done_out, uint8_t *trunc_out);
 

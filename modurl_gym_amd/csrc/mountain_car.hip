@@ -226,10 +226,14 @@ mountaincar_step4_kernel(MountainCarDev d, const uint32_t* __restrict__ act, flo
 // action word in, reward / done / truncated (and optionally the observation) out.  Same per-env function and the
 // same in-place auto-reset as mountaincar_step_kernel<4, CONT>, hence bit-identical to K separate steps.
 typedef uint32_t mc_u32x4 __attribute__((ext_vector_type(4)));
-template <bool CONT>
+// mgym_rollout_linear: the action comes from the observation the env holds before the step instead of a table.  Discrete(3): the index of the largest of
+// the three scores s_j = (w[j][0] * position + w[j][1] * velocity) + b[j] (the first of equal ones); Box(-1, 1): the one score itself as the force (the
+// step clamps it like any action).  f32, in that order, nothing fused.
+struct McLinearPolicy { float w[3][2], b[3]; };
+template <bool CONT, bool LINEAR = false>
 __global__ void __launch_bounds__(kBlock)
 mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, int K, float* __restrict__ obs_out, float* __restrict__ rew,
-                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, McLinearPolicy lin = McLinearPolicy{}, uint32_t* __restrict__ act_out = nullptr) {
     const uint64_t groups = d.n / 4;  // n % 4 == 0 is required by the host wrapper
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
@@ -240,8 +244,24 @@ mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, i
         float ps[4] = {vp.x, vp.y, vp.z, vp.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
         for (int t = 0; t < K; ++t) {
             const uint64_t off = (uint64_t)t * d.n + i0;
-            mc_u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const mc_u32x4*>(act + off));
-            uint32_t a[4] = {va.x, va.y, va.z, va.w}, dn[4];
+            uint32_t a[4], dn[4];
+            if constexpr (LINEAR) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float s0 = (lin.w[0][0] * ps[k] + lin.w[0][1] * vs[k]) + lin.b[0];
+                    if constexpr (CONT) a[k] = __float_as_uint(s0);
+                    else {
+                        const float s1 = (lin.w[1][0] * ps[k] + lin.w[1][1] * vs[k]) + lin.b[1], s2 = (lin.w[2][0] * ps[k] + lin.w[2][1] * vs[k]) + lin.b[2];
+                        uint32_t best = s1 > s0 ? 1u : 0u;
+                        const float sb = s1 > s0 ? s1 : s0;
+                        a[k] = s2 > sb ? 2u : best;
+                    }
+                }
+                if (act_out) __builtin_nontemporal_store(mc_u32x4{a[0], a[1], a[2], a[3]}, reinterpret_cast<mc_u32x4*>(act_out + off));
+            } else {
+                mc_u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const mc_u32x4*>(act + off));
+                a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w;
+            }
             float r[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -393,8 +413,25 @@ struct MountainCarEnv final : Env {
         bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
         if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
         dim3 gv(grid_for(n / 4)), b(kBlock);
-        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
-        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr);
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    int rollout_linear(const float* policy, int K, void* actions_out, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        uint32_t* ao = static_cast<uint32_t*>(actions_out);
+        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16)) {
+            set_last_error("mgym_rollout_linear: n_envs must be a multiple of 4 and the buffers 16-byte aligned");
+            return MGYM_ERR_BAD_ARG;
+        }
+        McLinearPolicy lin{};
+        const int rows = continuous ? 1 : 3;   // policy: `rows` rows of (w_position, w_velocity, bias)
+        for (int j = 0; j < rows; ++j) { lin.w[j][0] = policy[3 * j + 0]; lin.w[j][1] = policy[3 * j + 1]; lin.b[j] = policy[3 * j + 2]; }
+        dim3 gv(grid_for(n / 4)), b(kBlock);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, true>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao);
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, true>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

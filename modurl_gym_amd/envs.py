@@ -185,8 +185,13 @@ class VecEnv:
                                               _ptr(done_out), _ptr(trunc_out)))
 
     def rollout_linear_device(self, policy, K, actions_out=None, obs_out=None, reward_out=None, done_out=None, trunc_out=None):
-        """K fused steps under the on-device linear policy (mgym_rollout_linear; CartPole): policy = obs_dim weights + bias (host floats)."""
-        pol = (C.c_float * (self.obs_dim + 1))(*[float(v) for v in policy])
+        """K fused steps under the on-device linear policy (mgym_rollout_linear): policy = obs_dim weights + bias (CartPole: action 1 if the score is
+        positive; MountainCarContinuous: the score is the force), or one such row per action (MountainCar: the index of the largest score).  Host floats."""
+        n_pol = 3 * (self.obs_dim + 1) if self.kind == L.MOUNTAINCAR else self.obs_dim + 1   # MountainCar: a row of (weights, bias) per action
+        pol_in = np.asarray(policy, np.float32).ravel()
+        if pol_in.size != n_pol:
+            raise ValueError(f"policy must hold {n_pol} floats for this family, got {pol_in.size}")
+        pol = (C.c_float * n_pol)(*[float(v) for v in pol_in])
         _check(self._lib.mgym_rollout_linear(self._h, pol, int(K), _ptr(actions_out), _ptr(obs_out), _ptr(reward_out), _ptr(done_out),
                                              _ptr(trunc_out)))
 

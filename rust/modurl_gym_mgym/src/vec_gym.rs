@@ -142,13 +142,15 @@ impl VecGym {
         check(unsafe { mgym_rollout(self.env, actions, k, obs, reward, done, truncated) })
     }
 
-    /// K fused steps under an on-device linear policy (CartPole; `mgym_rollout_linear`): `policy` = 4 weights + bias; the loop
-    /// `let a = policy(&obs); env.step(a)` of cartpole.rs:251-348 without leaving the GPU.
+    /// K fused steps under an on-device linear policy (`mgym_rollout_linear`): the loop `let a = policy(&obs); env.step(a)` of
+    /// cartpole.rs:251-348 / mountain_car.rs:293-330 without leaving the GPU.  `policy`: CartPole 4 weights + bias (action 1 if the score
+    /// is positive); MountainCar three rows of (w_position, w_velocity, bias), the action is the index of the largest score;
+    /// MountainCarContinuous one such row, the score is the force.
     /// # Safety
-    /// the output pointers are device pointers of `[K][n]` (`[K][4][n]` for `obs`) elements, or null.
+    /// the output pointers are device pointers of `[K][n]` (`[K][obs_dim][n]` for `obs`) elements, or null.
     pub unsafe fn rollout_linear(
         &mut self,
-        policy: &[f32; 5],
+        policy: &[f32],
         k: i32,
         actions_out: *mut c_void,
         obs: *mut f32,
@@ -156,6 +158,10 @@ impl VecGym {
         done: *mut u8,
         truncated: *mut u8,
     ) -> Result<(), MgymError> {
+        let want: usize = if self.cfg.kind == MGYM_MOUNTAINCAR { 9 } else { (self.spec.obs_dim + 1) as usize };
+        if policy.len() != want {
+            return Err(MgymError { status: MGYM_ERR_BAD_ARG, message: format!("rollout_linear: {} policy floats for this family, got {}", want, policy.len()) });
+        }
         check(unsafe { mgym_rollout_linear(self.env, policy.as_ptr(), k, actions_out, obs, reward, done, truncated) })
     }
     /// K fused steps under the on-device uniform random policy (CartPole; `mgym_rollout_uniform`): no action table.

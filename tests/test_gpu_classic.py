@@ -650,4 +650,42 @@ def test_rollout_linear_policy_equals_a_stepping_loop_with_the_same_weights_and_
             obs = o
     assert fused.episode_count() == loop.episode_count() > n // 2   # most envs fell at least once
     with pytest.raises(mg.MgymError):
-        mg.VecEnv(mg.MOUNTAINCAR, 8).rollout_linear(pol[:3], 4)   # CartPole only
+        mg.VecEnv(mg.LUNARLANDER, 8).rollout_linear(np.zeros(9, np.float32), 4)   # classic control only
+
+
+@pytest.mark.parametrize("kind,okind", [(mg.MOUNTAINCAR, ora.MOUNTAINCAR), (mg.MOUNTAINCAR_CONT, ora.MOUNTAINCAR_CONT)])
+def test_rollout_linear_policy_for_mountain_car_equals_a_stepping_loop_and_the_oracle(kind, okind):
+    """mgym_rollout_linear for the MountainCar families (mountain_car.rs:293-330 with the policy in front): Discrete(3) — the index of the largest of three
+    scores (w_j0 position + w_j1 velocity) + b_j, the first of equal ones; Box(-1, 1) — the one score as the force.  Same f32 expression in numpy (every
+    operation rounded, nothing fused) driving mgym_step and the oracle must give the same actions, observations, rewards and flags.  The discrete policy
+    is the energy-pumping one (push with the velocity), so cars reach the goal and fused resets happen."""
+    n, K = 4096, 64
+    cont = kind == mg.MOUNTAINCAR_CONT
+    pol = np.array([0.0, 40.0, 0.01] if cont else [[0.0, -30.0, 0.0], [0.0, 0.0, 1e-4], [0.0, 30.0, 0.0]], np.float32)
+    fused, loop = mg.VecEnv(kind, n, seed=33, auto_reset=True), mg.VecEnv(kind, n, seed=33, auto_reset=True)
+    ref = ora.OracleVec(okind, n, seed=33)
+    obs = loop.reset()
+    assert np.array_equal(fused.reset(), obs) and np.array_equal(ref.reset(nthreads=8), obs)
+    finished = 0
+    for rnd in range(5):
+        acts, gobs, grew, gdone, gtrunc = fused.rollout_linear(pol, K)
+        for t in range(K):
+            if cont:
+                a = ((pol[0] * obs[0] + pol[1] * obs[1]) + pol[2]).astype(np.float32)
+                assert np.array_equal(acts[t].view(np.float32).view(np.uint32), a.view(np.uint32)), f"round {rnd} step {t}: actions"
+            else:
+                s = [((pol[j, 0] * obs[0] + pol[j, 1] * obs[1]) + pol[j, 2]).astype(np.float32) for j in range(3)]
+                a = np.where(s[1] > s[0], 1, 0).astype(np.uint32)
+                a = np.where(s[2] > np.maximum(s[0], s[1]), 2, a).astype(np.uint32)
+                assert np.array_equal(acts[t], a), f"round {rnd} step {t}: actions"
+            o, r, d, tr = loop.step(a)
+            eo, er, ed, et = ref.step(a, nthreads=8)
+            m = (ed | et).astype(np.uint8)
+            ro = ref.reset(mask=m, nthreads=8)
+            eo = np.where(m.astype(bool)[None, :], ro, eo)
+            finished += int(m.sum())
+            for g, e, x, nm in zip((gobs[t], grew[t], gdone[t], gtrunc[t]), (o, r, d, tr), (eo, er, ed, et), ("obs", "reward", "done", "truncated")):
+                assert np.array_equal(g, e), f"round {rnd} step {t}: {nm} vs the stepping loop"
+                assert np.array_equal(g, x), f"round {rnd} step {t}: {nm} vs the oracle"
+            obs = o
+    assert finished > 0 and fused.episode_count() == loop.episode_count() == finished
