@@ -605,8 +605,9 @@ def main():
                     st.env.sync()
                     extra[f"lunar_lander_rollout_K{K_roll}"] = {
                         "env_steps_per_s": cnt * K_roll * reps / (rms * 1e-3), "us_per_step": rms * 1e3 / (K_roll * reps), "n_envs": cnt, "steps": K_roll * reps,
-                        "launches_per_rollout": 2, "vs_mgym_step": (ms / k) / (rms / (K_roll * reps)),
-                        "note": "mgym_rollout: one persistent launch per K steps, environments advance independently through device queues; "
+                        "launches_per_rollout": 4, "vs_mgym_step": (ms / k) / (rms / (K_roll * reps)),
+                        "note": "mgym_rollout: one persistent launch per K steps (counter reset, main waves, free-flight helper waves beside them, next step's contact list), "
+                                "environments advance independently through device queues; "
                                 "word-for-word equal to K mgym_step calls (tests/test_gpu_lunar_rollout.py); the launch ends with its last environments' chains, "
                                 "so longer rollouts amortise better"}
                     del acts_k, rw, dn, tr
