@@ -992,7 +992,7 @@ struct LunarLanderEnv final : Env {
     // multi-stream order are as fast or faster (524 288 envs, K = 64: 1.34 ms per step against 1.30; 1 Mi: 2.63 against 2.15: both bound by SIMD
     // occupancy there, and the step's free-flight kernel runs at two waves per SIMD; profiles/r04_lunarlander/rollout_by_population.txt)
     int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : -1;
-    int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : 1;   // free-flight helper waves beside the main launch (init)
+    int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : -1;   // free-flight helper waves beside the main launch: 0 never, 1 always, unset: by population (init)
     unsigned roll_helper_grid = 0;
     int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : 8;   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
     void* roll_ring = nullptr;
@@ -1170,6 +1170,9 @@ struct LunarLanderEnv final : Env {
             // free-flight steps at 46 us of SIMD time per 64 env-steps against 79 in a main wave, and the 768 main waves are busy with the contact
             // path throughout (35 of 45 ms).  Two SIMDs per CU for the helpers: 1.05 (the contact path is the larger share); four main waves per CU:
             // no helper ever becomes resident and the launch runs as before (0.71) — the helpers are an accelerator, never a dependency.
+            // Small populations end a launch with a longer tail than busy phase, and there a fourth main wave per CU is worth more than the helpers:
+            // 65 536 envs K = 16 0.71 | 0.81, 98 304: 0.66 | 0.70, 131 072: 0.72 | 0.64 (K = 8: 0.78 | 0.82), 196 608: 0.77 | 0.73 (K = 8: 0.90 | 0.85) — on from 163 840 envs.
+            if (roll_helper < 0) roll_helper = n >= 163840 ? 1 : 0;
             roll_helper_grid = 0;
             if (roll_helper && per_cu >= 4) {
                 const unsigned main_per_cu = LL_TUNE("MGYM_LL_ROLL_MAIN_PER_CU", 3u), help_per_cu = LL_TUNE("MGYM_LL_ROLL_HELPER_PER_CU", 2u);

@@ -17,12 +17,15 @@ def words(a):
     return a.view(np.uint32) if a.dtype == np.float32 else a
 
 
-@pytest.mark.parametrize("n,K,auto_reset", [(4096, 8, True), (4096, 16, True), (1000, 24, False), (97, 9, True), (1, 8, True)])
-def test_rollout_equals_k_steps_word_for_word(n, K, auto_reset):
-    # two handles with the same seed: one steps K times, the other makes one mgym_rollout call; then again from where they stand
+@pytest.mark.parametrize("n,K,auto_reset,helper", [(4096, 8, True, 0), (4096, 16, True, 1), (1000, 24, False, 1), (97, 9, True, 0), (1, 8, True, 1), (8192, 12, True, 1)])
+def test_rollout_equals_k_steps_word_for_word(n, K, auto_reset, helper, monkeypatch):
+    # two handles with the same seed: one steps K times, the other makes one mgym_rollout call; then again from where they stand.
+    # helper: with / without the free-flight helper waves beside the main launch (by default they come with populations from 163 840 envs)
     kw = dict(seed=321, enable_wind=True, auto_reset=auto_reset)
+    monkeypatch.setenv("MGYM_LL_ROLL_HELPER", str(helper))
     a_env, b_env = mg.VecEnv(mg.LUNARLANDER, n, **kw), mg.VecEnv(mg.LUNARLANDER, n, **kw)
-    assert a_env.info()["rollout"] == "persistent_launch"
+    monkeypatch.delenv("MGYM_LL_ROLL_HELPER")
+    assert a_env.info()["rollout"] == "persistent_launch" and (int(b_env.info()["rollout_helper_blocks"]) > 0) == (helper == 1 and n >= 64)
     assert np.array_equal(a_env.reset(), b_env.reset())
     rng = np.random.default_rng(5)
     for rep in range(6):
@@ -39,8 +42,11 @@ def test_rollout_equals_k_steps_word_for_word(n, K, auto_reset):
     a_env.close(), b_env.close()
 
 
-def test_rollout_soak_every_word_equals_the_oracle():
-    # 4 096 envs x 960 steps in rollouts of 16, skilled policy (landings asleep as well as crashes and fly-aways), fused auto-reset
+@pytest.mark.parametrize("helper", [0, 1])
+def test_rollout_soak_every_word_equals_the_oracle(helper, monkeypatch):
+    # 4 096 envs x 960 steps in rollouts of 16, skilled policy (landings asleep as well as crashes and fly-aways), fused auto-reset;
+    # without and with the free-flight helper waves
+    monkeypatch.setenv("MGYM_LL_ROLL_HELPER", str(helper))
     episodes, landed, crashed = soak(4096, 960, seed=77, rollout_k=16)
     assert episodes > 12000 and landed > 10 and crashed > 6000
 
@@ -104,13 +110,15 @@ def test_rollout_without_outputs_and_short_rollouts_fall_back():
     env.sync(), twin.sync()
 
 
-def test_rollout_captured_into_a_graph_replays_like_eager_rollouts():
+def test_rollout_captured_into_a_graph_replays_like_eager_rollouts(monkeypatch):
     """mgym_graph_begin / _end around mgym_rollout: the persistent launch and its free-flight helper waves (helper stream, fork / join by events
     recorded inside the capture) become one hipGraph; replays — state is read when the graph runs — must give the words of eager rollouts from the
     same state.  Actions and outputs are the captured device buffers, rewritten between replays."""
     n, K = 16384, 8
     kw = dict(seed=41, enable_wind=True, auto_reset=True)
+    monkeypatch.setenv("MGYM_LL_ROLL_HELPER", "1")   # (by default the helper waves come with populations from 163 840 envs)
     g_env, e_env = mg.VecEnv(mg.LUNARLANDER, n, **kw), mg.VecEnv(mg.LUNARLANDER, n, **kw)
+    monkeypatch.delenv("MGYM_LL_ROLL_HELPER")
     assert int(g_env.info()["rollout_helper_blocks"]) > 0
     assert np.array_equal(g_env.reset(), e_env.reset())
     rng = np.random.default_rng(8)

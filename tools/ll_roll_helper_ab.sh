@@ -1,14 +1,12 @@
 #!/bin/bash
-# (*GPU box*) mgym_rollout with / without the free-flight helper waves: parity first, then ms per step-equivalent at 262 144 envs
-O=gpurun_out/roll_helper_ab.txt; : > $O
-MGYM_LL_ROLL_HELPER=1 timeout -k 10 600 python -m pytest tests/test_gpu_lunar_rollout.py -x -q > gpurun_out/roll_helper_tests.log 2>&1 || { tail -5 gpurun_out/roll_helper_tests.log; exit 1; }
-tail -1 gpurun_out/roll_helper_tests.log >> $O
-t() { echo "== $*" >> $O; env "$@" MGYM_LL_ROLL_STATS=1 timeout -k 10 300 python tools/ll_roll_check.py time ${N:-262144} $K 6 2>&1 | grep -E "^n=|helper" | tail -2 >> $O; }
-for K in 64 16 8; do
-  export K
-  t MGYM_LL_ROLL_HELPER=0 || exit 1
-  t MGYM_LL_ROLL_HELPER=1 || exit 1
-  t MGYM_LL_ROLL_HELPER=1 MGYM_LL_ROLL_MAIN_PER_CU=2 MGYM_LL_ROLL_HELPER_PER_CU=4 || exit 1
-  t MGYM_LL_ROLL_HELPER=1 MGYM_LL_ROLL_MAIN_PER_CU=4 MGYM_LL_ROLL_HELPER_PER_CU=2 || exit 1
+# (*GPU box*) mgym_rollout with / without the free-flight helper waves by population and K: ms per step-equivalent (tools/ll_roll_check.py time)
+O=gpurun_out/roll_helper_by_population.txt; : > $O
+for N in ${SIZES:-32768 65536 98304 131072 196608}; do
+  for K in ${KS:-8 16}; do
+    for H in 0 1; do
+      echo "== $N envs K=$K MGYM_LL_ROLL_HELPER=$H" >> $O
+      MGYM_LL_ROLL_HELPER=$H timeout -k 10 300 python tools/ll_roll_check.py time $N $K 10 2>&1 | grep "^n=" >> $O || exit 1
+    done
+  done
 done
 echo "roll_helper_ab rc=$?"
