@@ -153,9 +153,13 @@ int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, 
 /* mgym_rollout under an on-device uniform random policy (SURVEY §8f-1 "policy hook": random), so a rollout needs no
  * [K][n] action table: env with global id g takes, at step t of this call, bit (t % 32) of word (g % 4) of
  * Philox4x32-10(key = policy_seed; counter = (g & ~3, number of earlier mgym_rollout_uniform calls on this handle,
- * 0x40000000 + t / 32)).  actions_out ([K][n_envs] uint32, may be NULL) receives the drawn actions.  CartPole only
- * (Discrete(2)); n_envs and env_id_base must be multiples of 4.  Reference loop it fuses: a trainer calling
- * `action_space().sample()` then `step()` (cartpole.rs:251-348, 350-356). */
+ * 0x40000000 + t / 32)).  actions_out ([K][n_envs] uint32, may be NULL) receives the drawn actions.  n_envs and env_id_base must be
+ * multiples of 4.  Reference loop it fuses: a trainer calling `action_space().sample()` then `step()` (cartpole.rs:251-348, 350-356;
+ * mountain_car.rs:293-330).
+ * MountainCar (Discrete(3)): same key and the first two counter words, fourth word 0x40000000 + t / 2; env g takes half (t % 2) (low half first)
+ * of word (g % 4), h, and the action (3 h) >> 16 — every action within 2^-16 of probability 1/3.  MountainCarContinuous (Box(-1, 1)): fourth
+ * word 0x40000000 + t, the top 24 bits u of word (g % 4) give the force u * 2^-23 - 1 (actions_out then holds f32 words).
+ * LunarLander: MGYM_ERR_BAD_ARG. */
 int mgym_rollout_uniform(mgym_env *env, uint64_t policy_seed, int32_t K, void *actions_out, float *obs_out,
                          float *reward_out, uint8_t *done_out, uint8_t *trunc_out);
 

@@ -230,10 +230,18 @@ typedef uint32_t mc_u32x4 __attribute__((ext_vector_type(4)));
 // the three scores s_j = (w[j][0] * position + w[j][1] * velocity) + b[j] (the first of equal ones); Box(-1, 1): the one score itself as the force (the
 // step clamps it like any action).  f32, in that order, nothing fused.
 struct McLinearPolicy { float w[3][2], b[3]; };
-template <bool CONT, bool LINEAR = false>
+// mgym_rollout_uniform: the lane's four envs (global ids g .. g + 3, g a multiple of 4) share one Philox stream keyed by the policy seed, counter =
+// (g, number of earlier mgym_rollout_uniform calls on this handle, SLOT_POLICY + block).  Discrete(3): step t takes, for env g + k, half (t % 2) of word k
+// of block t / 2 (low half first), h, and the action (3 h) >> 16 — each action within 2^-16 of 1/3.  Box(-1, 1): word k of block t, top 24 bits u:
+// the force u 2^-23 - 1, uniform over the multiples of 2^-23 in [-1, 1).
+enum { MC_ROLL_TABLE = 0, MC_ROLL_LINEAR = 1, MC_ROLL_UNIFORM = 2 };
+struct McUniformPolicy { uint64_t seed; uint32_t call; };
+template <bool CONT, int POLICY = MC_ROLL_TABLE>
 __global__ void __launch_bounds__(kBlock)
 mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, int K, float* __restrict__ obs_out, float* __restrict__ rew,
-                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, McLinearPolicy lin = McLinearPolicy{}, uint32_t* __restrict__ act_out = nullptr) {
+                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out, McLinearPolicy lin = McLinearPolicy{}, uint32_t* __restrict__ act_out = nullptr,
+                           McUniformPolicy uni = McUniformPolicy{}) {
+    constexpr bool LINEAR = POLICY == MC_ROLL_LINEAR;
     const uint64_t groups = d.n / 4;  // n % 4 == 0 is required by the host wrapper
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
@@ -242,10 +250,21 @@ mountaincar_rollout_kernel(MountainCarDev d, const uint32_t* __restrict__ act, i
         const uint64_t i0 = g * 4;
         float4 vp = *reinterpret_cast<const float4*>(d.pos + i0), vv = *reinterpret_cast<const float4*>(d.vel + i0);
         float ps[4] = {vp.x, vp.y, vp.z, vp.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
+        Philox4 bits{};
         for (int t = 0; t < K; ++t) {
             const uint64_t off = (uint64_t)t * d.n + i0;
             uint32_t a[4], dn[4];
-            if constexpr (LINEAR) {
+            if constexpr (POLICY == MC_ROLL_UNIFORM) {
+                const uint64_t gid = d.env_id_base + i0;
+                if (CONT || (t & 1) == 0)
+                    bits = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), uni.call, SLOT_POLICY + (uint32_t)(CONT ? t : t >> 1), (uint32_t)uni.seed, (uint32_t)(uni.seed >> 32));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (CONT) a[k] = __float_as_uint((float)(bits.w[k] >> 8) * 1.1920928955078125e-07f - 1.0f);
+                    else a[k] = ((((t & 1) ? bits.w[k] >> 16 : bits.w[k] & 0xffffu)) * 3u) >> 16;
+                }
+                if (act_out) __builtin_nontemporal_store(mc_u32x4{a[0], a[1], a[2], a[3]}, reinterpret_cast<mc_u32x4*>(act_out + off));
+            } else if constexpr (LINEAR) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float s0 = (lin.w[0][0] * ps[k] + lin.w[0][1] * vs[k]) + lin.b[0];
@@ -413,8 +432,24 @@ struct MountainCarEnv final : Env {
         bool vec_ok = n % 4 == 0 && aligned(act, 16) && aligned(reward, 16) && aligned(done, 4) && aligned(trunc, 4) && aligned(obs_out, 16);
         if (!vec_ok) return Env::rollout(actions, K, obs_out, reward, done, trunc);  // K plain steps
         dim3 gv(grid_for(n / 4)), b(kBlock);
-        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr);
-        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, false>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, MC_ROLL_TABLE>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr, McUniformPolicy{});
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, MC_ROLL_TABLE>), gv, b, 0, stream, dev, act, K, obs_out, reward, done, trunc, McLinearPolicy{}, (uint32_t*)nullptr, McUniformPolicy{});
+        MGYM_HIP(hipGetLastError());
+        return MGYM_OK;
+    }
+
+    uint32_t policy_calls = 0;  // mgym_rollout_uniform calls so far (Philox counter word of the policy stream)
+    int rollout_uniform(uint64_t policy_seed, int K, void* actions_out, float* obs_out, float* reward, uint8_t* done, uint8_t* trunc) override {
+        if (n == 0 || K == 0) return MGYM_OK;
+        uint32_t* ao = static_cast<uint32_t*>(actions_out);
+        if (n % 4 != 0 || !aligned(ao, 16) || !aligned(reward, 16) || !aligned(done, 4) || !aligned(trunc, 4) || !aligned(obs_out, 16)) {
+            set_last_error("mgym_rollout_uniform: n_envs must be a multiple of 4 and the buffers 16-byte aligned");
+            return MGYM_ERR_BAD_ARG;
+        }
+        const McUniformPolicy uni{policy_seed, policy_calls++};
+        dim3 gv(grid_for(n / 4)), b(kBlock);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, MC_ROLL_UNIFORM>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, McLinearPolicy{}, ao, uni);
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, MC_ROLL_UNIFORM>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, McLinearPolicy{}, ao, uni);
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }
@@ -430,8 +465,8 @@ struct MountainCarEnv final : Env {
         const int rows = continuous ? 1 : 3;   // policy: `rows` rows of (w_position, w_velocity, bias)
         for (int j = 0; j < rows; ++j) { lin.w[j][0] = policy[3 * j + 0]; lin.w[j][1] = policy[3 * j + 1]; lin.b[j] = policy[3 * j + 2]; }
         dim3 gv(grid_for(n / 4)), b(kBlock);
-        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, true>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao);
-        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, true>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao);
+        if (continuous) hipLaunchKernelGGL((mountaincar_rollout_kernel<true, MC_ROLL_LINEAR>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao, McUniformPolicy{});
+        else hipLaunchKernelGGL((mountaincar_rollout_kernel<false, MC_ROLL_LINEAR>), gv, b, 0, stream, dev, (const uint32_t*)nullptr, K, obs_out, reward, done, trunc, lin, ao, McUniformPolicy{});
         MGYM_HIP(hipGetLastError());
         return MGYM_OK;
     }

@@ -180,7 +180,7 @@ class VecEnv:
                                       _ptr(trunc_out)))
 
     def rollout_uniform_device(self, policy_seed, K, actions_out=None, obs_out=None, reward_out=None, done_out=None, trunc_out=None):
-        """K fused steps under the on-device uniform random policy (mgym_rollout_uniform; CartPole)."""
+        """K fused steps under the on-device uniform random policy (mgym_rollout_uniform; CartPole, MountainCar, MountainCarContinuous)."""
         _check(self._lib.mgym_rollout_uniform(self._h, int(policy_seed), int(K), _ptr(actions_out), _ptr(obs_out), _ptr(reward_out),
                                               _ptr(done_out), _ptr(trunc_out)))
 

@@ -164,7 +164,7 @@ impl VecGym {
         }
         check(unsafe { mgym_rollout_linear(self.env, policy.as_ptr(), k, actions_out, obs, reward, done, truncated) })
     }
-    /// K fused steps under the on-device uniform random policy (CartPole; `mgym_rollout_uniform`): no action table.
+    /// K fused steps under the on-device uniform random policy (`mgym_rollout_uniform`; CartPole, MountainCar, MountainCarContinuous): no action table.
     /// `actions_out` (`[K][n]` u32, may be null) receives the drawn actions.
     #[allow(clippy::too_many_arguments)]
     pub fn rollout_uniform(

@@ -606,7 +606,46 @@ def test_rollout_uniform_policy_equals_oracle_driven_by_the_same_bits(auto_reset
     with pytest.raises(mg.MgymError):
         mg.VecEnv(mg.CARTPOLE, 8, env_id_base=2).rollout_uniform(1, 4)   # env_id_base must be a multiple of 4
     with pytest.raises(mg.MgymError):
-        mg.VecEnv(mg.MOUNTAINCAR, 8).rollout_uniform(1, 4)               # CartPole only
+        mg.VecEnv(mg.LUNARLANDER, 8).rollout_uniform(1, 4)               # classic control only
+
+
+@pytest.mark.parametrize("kind,okind", [(mg.MOUNTAINCAR, ora.MOUNTAINCAR), (mg.MOUNTAINCAR_CONT, ora.MOUNTAINCAR_CONT)])
+def test_rollout_uniform_policy_for_mountain_car_equals_oracle_driven_by_the_same_draws(kind, okind):
+    """mgym_rollout_uniform for the MountainCar families (include/mgym.h): Discrete(3) — 16-bit halves of the policy stream's words, action (3 h) >> 16;
+    Box(-1, 1) — the top 24 bits u of a word, force u 2^-23 - 1.  The draws are restated here with the oracle's Philox; the oracle stepped with them
+    (fused auto-reset) must give the engine's words."""
+    n, K, base, seed = 1024, 37, 8192, 0x1234ABCD5678
+    cont = kind == mg.MOUNTAINCAR_CONT
+    env = mg.VecEnv(kind, n, seed=19, env_id_base=base, auto_reset=True)
+    ref = ora.OracleVec(okind, n, seed=19, env_id_base=base)
+    env.reset(), ref.reset()
+    for call in range(2):
+        acts, obs, rew, done, trunc = env.rollout_uniform(seed, K)
+        exp = np.zeros((K, n), np.uint32)
+        for g0 in range(0, n, 4):
+            gid = base + g0
+            for t in range(K):
+                w = ora.philox([gid & 0xFFFFFFFF, gid >> 32, call, 0x40000000 + (t if cont else t // 2)], [seed & 0xFFFFFFFF, seed >> 32])
+                for k in range(4):
+                    if cont:
+                        exp[t, g0 + k] = np.float32(np.float32(int(w[k]) >> 8) * np.float32(2.0 ** -23) - np.float32(1.0)).view(np.uint32)
+                    else:
+                        h = (int(w[k]) >> 16) if (t & 1) else (int(w[k]) & 0xFFFF)
+                        exp[t, g0 + k] = (h * 3) >> 16
+        assert np.array_equal(acts, exp), f"call {call}: drawn actions"
+        if cont:
+            f = acts.view(np.float32)
+            assert f.min() >= -1.0 and f.max() < 1.0 and abs(float(f.mean())) < 0.02
+        else:
+            assert acts.max() == 2 and all(0.31 < float((acts == j).mean()) < 0.36 for j in range(3))
+        for t in range(K):
+            a = exp[t].view(np.float32) if cont else exp[t]
+            eo, er, ed, et = ref.step(a)
+            m = (ed | et).astype(np.uint8)
+            ref.reset(mask=m)
+            assert np.array_equal(rew[t], er) and np.array_equal(done[t], ed) and np.array_equal(trunc[t], et), f"call {call} step {t}"
+            assert np.array_equal(obs[t], ref.get_state()[:2]), f"call {call} step {t}: observation"
+    assert np.array_equal(env.get_state().view(np.uint32), ref.get_state().view(np.uint32))
 
 
 def test_discrete_actions_must_be_integers():
