@@ -23,9 +23,11 @@ def test_rollout_equals_k_steps_word_for_word(n, K, auto_reset, helper, monkeypa
     # helper: with / without the free-flight helper waves beside the main launch (by default they come with populations from 163 840 envs)
     kw = dict(seed=321, enable_wind=True, auto_reset=auto_reset)
     monkeypatch.setenv("MGYM_LL_ROLL_HELPER", str(helper))
+    monkeypatch.setenv("MGYM_LL_ROLLOUT_MIN_K", "8")   # (by default populations below 163 840 envs take rollouts shorter than 12 steps as K steps)
     a_env, b_env = mg.VecEnv(mg.LUNARLANDER, n, **kw), mg.VecEnv(mg.LUNARLANDER, n, **kw)
     monkeypatch.delenv("MGYM_LL_ROLL_HELPER")
-    assert a_env.info()["rollout"] == "persistent_launch" and (int(b_env.info()["rollout_helper_blocks"]) > 0) == (helper == 1 and n >= 64)
+    monkeypatch.delenv("MGYM_LL_ROLLOUT_MIN_K")
+    assert a_env.info()["rollout"] == "persistent_launch" and a_env.info()["rollout_min_k"] == "8" and (int(b_env.info()["rollout_helper_blocks"]) > 0) == (helper == 1 and n >= 64)
     assert np.array_equal(a_env.reset(), b_env.reset())
     rng = np.random.default_rng(5)
     for rep in range(6):
@@ -96,10 +98,10 @@ def test_rollout_without_outputs_and_short_rollouts_fall_back():
     env = mg.VecEnv(mg.LUNARLANDER, n, seed=3, enable_wind=False, auto_reset=True)
     twin = mg.VecEnv(mg.LUNARLANDER, n, seed=3, enable_wind=False, auto_reset=True)
     env.reset(), twin.reset()
-    acts = np.random.default_rng(0).integers(0, 4, (10, n)).astype(np.uint32)
+    acts = np.random.default_rng(0).integers(0, 4, (14, n)).astype(np.uint32)
     da = mg.DeviceArray.from_numpy(acts, 0)
-    env.rollout_device(da, 10, None, None, None, None)     # every output pointer NULL: only the state advances
-    for k in range(10):
+    env.rollout_device(da, 14, None, None, None, None)     # every output pointer NULL: only the state advances (14 >= rollout_min_k: the persistent launch)
+    for k in range(14):
         twin.step(acts[k])
     assert np.array_equal(words(env.observation()), words(twin.observation()))
     short = np.random.default_rng(1).integers(0, 4, (3, n)).astype(np.uint32)   # K below rollout_min_k: K x mgym_step inside the engine
@@ -116,9 +118,11 @@ def test_rollout_captured_into_a_graph_replays_like_eager_rollouts(monkeypatch):
     same state.  Actions and outputs are the captured device buffers, rewritten between replays."""
     n, K = 16384, 8
     kw = dict(seed=41, enable_wind=True, auto_reset=True)
-    monkeypatch.setenv("MGYM_LL_ROLL_HELPER", "1")   # (by default the helper waves come with populations from 163 840 envs)
+    monkeypatch.setenv("MGYM_LL_ROLL_HELPER", "1")   # (by default the helper waves come with populations from 163 840 envs,
+    monkeypatch.setenv("MGYM_LL_ROLLOUT_MIN_K", "8")  #  and smaller ones take rollouts shorter than 12 steps as K steps)
     g_env, e_env = mg.VecEnv(mg.LUNARLANDER, n, **kw), mg.VecEnv(mg.LUNARLANDER, n, **kw)
     monkeypatch.delenv("MGYM_LL_ROLL_HELPER")
+    monkeypatch.delenv("MGYM_LL_ROLLOUT_MIN_K")
     assert int(g_env.info()["rollout_helper_blocks"]) > 0
     assert np.array_equal(g_env.reset(), e_env.reset())
     rng = np.random.default_rng(8)
