@@ -62,7 +62,11 @@ constexpr int kRollTraceLen = 512;
 enum { RT_SEED = 1, RT_CONTACT, RT_LIGHT, RT_RESET, RT_FREE, RT_IDLE, RT_END, RT_TOI };
 constexpr uint32_t kRollMaxK = 240;          // step index in the top byte of an entry (0xff.. = empty is never a valid entry)
 constexpr uint32_t kRollEnvMask = 0xffffffu;
-constexpr long long kRollTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a wave that waits this long gives up loudly
+// 120 s of the 100 MHz wall clock: a wave that waits this long gives up loudly (sticky internal error, the launch drains).  The bound only has to turn a deadlock into
+// an error before anything outside kills the process; it must NOT be near anything a healthy launch can see: the clock runs on while the waves do not (a launch of this
+// round stood still for ~3 s in the middle of its register-only sweeps — whole-GPU, every phase of every wave 50-150 x longer — and the 3 s bound of the time turned that
+// stall into an abort; profiles/r04_lunarlander/rollout_stall_record.txt).
+constexpr long long kRollTimeoutTicks = 12000000000ll;
 
 
 }  // namespace mgym
