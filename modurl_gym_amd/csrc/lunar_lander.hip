@@ -994,7 +994,7 @@ struct LunarLanderEnv final : Env {
     int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : -1;
     int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : -1;   // free-flight helper waves beside the main launch: 0 never, 1 always, unset: by population (init)
     unsigned roll_helper_grid = 0;
-    int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : 8;   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
+    int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : -1;   // (-1: 8 from 163 840 envs, 12 below: init)   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
     void* roll_ring = nullptr;
     void* roll_ctl = nullptr;
     void* roll_vc_far = nullptr;
@@ -1125,6 +1125,9 @@ struct LunarLanderEnv final : Env {
         // far-constraint workspace per wave.  (Records are addressed by 32-bit byte offsets there: n_pad x 1152 B < 4 GiB.)
         if (roll_enabled < 0) roll_enabled = n < 491520 ? 1 : 0;
         roll_enabled = roll_enabled && !general_only && n > 0 && n <= kRollEnvMask && (uint64_t)n_pad * kRec * 4ull < 0xffffffffull;
+        // 8-step rollouts of small populations are no faster than 8 steps (131 072 envs: 0.88 ms per step-equivalent against 0.85, 65 536: 0.80 / 0.80; K = 16: 0.70 / 0.85
+        // and 0.62 / 0.79): the persistent launch from 12 steps there, from 8 at 163 840 envs and more
+        if (roll_min_k < 0) roll_min_k = n >= 163840 ? 8 : 12;
         if (roll_enabled) {
             uint64_t cap = 64;
             while (cap < n) cap <<= 1;
@@ -1146,14 +1149,16 @@ struct LunarLanderEnv final : Env {
             rq.toi_split = LL_TUNE("MGYM_LL_ROLL_TOI_SPLIT", 7u);
             rq.toi_min = LL_TUNE("MGYM_LL_ROLL_TOI_MIN", 24u);
             rq.keep_min = LL_TUNE("MGYM_LL_ROLL_KEEP_MIN", 24u);
-            rq.keep = LL_TUNE("MGYM_LL_ROLL_KEEP", 1u);
+            // (with the helper waves on — the main waves live on the contact path — light batches that keep their residents too, and a rotation after 3 steps: 262 144 envs
+            // K = 64 0.68 -> 0.62 ms per step, K = 16 0.77 -> 0.76, K = 8 unchanged; profiles/r04_lunarlander/rollout_tuning_with_helper_waves.txt)
+            rq.keep = LL_TUNE("MGYM_LL_ROLL_KEEP", 3u);
             rq.fair = LL_TUNE("MGYM_LL_ROLL_FAIR", 0u);
             rq.heavy_narrow = LL_TUNE("MGYM_LL_ROLL_HEAVY_NARROW", 12u);
             if (rq.heavy_narrow > rq.heavy_max) rq.heavy_narrow = rq.heavy_max;
             if (rq.heavy_narrow < 1u) rq.heavy_narrow = 1u;
             rq.reset_min = LL_TUNE("MGYM_LL_ROLL_RESET_MIN", 16u);
             rq.free_min = LL_TUNE("MGYM_LL_ROLL_FREE_MIN", 32u);
-            rq.residency = LL_TUNE("MGYM_LL_ROLL_RESIDENCY", 2u);
+            rq.residency = LL_TUNE("MGYM_LL_ROLL_RESIDENCY", 3u);
             rq.refill_min = LL_TUNE("MGYM_LL_ROLL_REFILL_MIN", 8u);
             rq.debug = LL_TUNE("MGYM_LL_ROLL_DEBUG", 0u);
             ll_rollout_ring_init(stream, rq);
