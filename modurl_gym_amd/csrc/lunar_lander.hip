@@ -931,6 +931,7 @@ struct LunarLanderEnv final : Env {
     void* kdev = nullptr;
     void* vc_far_base = nullptr;
     hipStream_t aux = nullptr;          // helper stream of the overlapped launch order
+    hipStream_t roll_aux = nullptr;     // the rollout's free-flight helper waves: a stream of their own at the default priority (created with the helpers)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* shadow_base = nullptr;        // staged resets: shadow state columns [C_COUNT][n_pad] and observation [8][n_pad]
     void* shadow_obs = nullptr;
@@ -1015,6 +1016,7 @@ struct LunarLanderEnv final : Env {
         if (aux) (void)hipStreamDestroy(aux);
         if (env_class) (void)hipFree(env_class);
         if (aux2) { (void)hipStreamSynchronize(aux2); (void)hipStreamDestroy(aux2); }
+        if (roll_aux) { (void)hipStreamSynchronize(roll_aux); (void)hipStreamDestroy(roll_aux); }
         if (shadow_base) (void)hipFree(shadow_base);
         if (shadow_obs) (void)hipFree(shadow_obs);
         if (ev_prep) (void)hipEventDestroy(ev_prep);
@@ -1184,6 +1186,8 @@ struct LunarLanderEnv final : Env {
                 if ((int)main_per_cu < per_cu && main_per_cu >= 1) g = (uint64_t)main_per_cu * (uint64_t)prop.multiProcessorCount;
                 roll_helper_grid = help_per_cu * (unsigned)prop.multiProcessorCount;
                 if ((uint64_t)roll_helper_grid * 64 > n) roll_helper_grid = (unsigned)(n / 64);
+                // (MGYM_LL_ROLL_HELPER_LOWPRIO=1: on the step's helper stream, which has the lowest priority)
+                if (roll_helper_grid && !(getenv("MGYM_LL_ROLL_HELPER_LOWPRIO") && atoi(getenv("MGYM_LL_ROLL_HELPER_LOWPRIO")))) MGYM_HIP(hipStreamCreateWithFlags(&roll_aux, hipStreamNonBlocking));
             }
             rq.helper_min = LL_TUNE("MGYM_LL_ROLL_HELPER_MIN", 256u);
             if (LL_TUNE("MGYM_LL_ROLL_GRID", 0u)) g = (uint64_t)LL_TUNE("MGYM_LL_ROLL_GRID", 0u);
@@ -1217,9 +1221,10 @@ struct LunarLanderEnv final : Env {
             if (roll_helper_grid) MGYM_HIP(hipEventRecord(ev_fork, stream));
             ll_rollout_launch(stream, roll_grid, rd, io, q);
             if (roll_helper_grid) {   // the helper waves beside it, on the helper stream (fork / join by events: stream-ordered for the caller, capturable)
-                MGYM_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-                ll_rollout_helper_launch(aux, roll_helper_grid, rd, io, q);
-                MGYM_HIP(hipEventRecord(ev_join, aux));
+                hipStream_t hs = roll_aux ? roll_aux : aux;
+                MGYM_HIP(hipStreamWaitEvent(hs, ev_fork, 0));
+                ll_rollout_helper_launch(hs, roll_helper_grid, rd, io, q);
+                MGYM_HIP(hipEventRecord(ev_join, hs));
                 MGYM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
             }
         }
