@@ -993,7 +993,10 @@ struct LunarLanderEnv final : Env {
     // multi-stream order are as fast or faster (524 288 envs, K = 64: 1.34 ms per step against 1.30; 1 Mi: 2.63 against 2.15: both bound by SIMD
     // occupancy there, and the step's free-flight kernel runs at two waves per SIMD; profiles/r04_lunarlander/rollout_by_population.txt)
     int roll_enabled = getenv("MGYM_LL_ROLLOUT") ? atoi(getenv("MGYM_LL_ROLLOUT")) : -1;
-    int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : -1;   // free-flight helper waves beside the main launch: 0 never, 1 always, unset: by population (init)
+    // free-flight helper waves beside the main launch: 0 never (the default), 1 always, -1 by population (from 163 840 envs).  OFF by default: with them a launch hung —
+    // waves of both kernels standing still — once in ~75 stress runs (tools/ll_roll_stress.sh: 4 hangs in ~350 runs, on either helper stream), never in 100 runs without them
+    // or in the day's hundreds of runs before they existed; the cause was not found in the time left of round 4.  They are worth 4-6 %.
+    int roll_helper = getenv("MGYM_LL_ROLL_HELPER") ? atoi(getenv("MGYM_LL_ROLL_HELPER")) : 0;
     unsigned roll_helper_grid = 0;
     int roll_min_k = getenv("MGYM_LL_ROLLOUT_MIN_K") ? atoi(getenv("MGYM_LL_ROLLOUT_MIN_K")) : -1;   // (-1: 8 from 163 840 envs, 12 below: init)   // shorter rollouts: K x step() (the launch's last environments take their last steps alone: ~2-3 ms, measured)
     void* roll_ring = nullptr;
