@@ -145,7 +145,8 @@ int mgym_step(mgym_env *env, const void *actions, float *obs_out, float *reward_
  * index each is at) — a step of mgym_step ends with its slowest environment, K steps of mgym_rollout cost the mean one.  Per-environment
  * results are those of K mgym_step calls, word for word (the loop being fused: lunar_lander.rs:919-1167 called K times).  Which form runs is the
  * engine's choice by K and population (mgym_get_info: rollout, rollout_min_k, rollout_waves, rollout_helper_blocks): K >= 8 (K >= 12 below 163 840 envs) below 491 520 envs per handle
- * the persistent launch, otherwise K steps. */
+ * the persistent launch, otherwise K steps — and always K steps while the stream is being captured (mgym_graph_begin or an external capture): replays
+ * of a captured persistent launch aborted inside the HIP runtime at the end of round 4, unexplained; the words are the same either way. */
 int mgym_rollout(mgym_env *env, const void *actions, int32_t K, float *obs_out, float *reward_out,
                  uint8_t *done_out, uint8_t *trunc_out);
 

@@ -239,6 +239,14 @@ int mgym_rollout(mgym_env* env, const void* actions, int32_t K, float* obs_out, 
     ENV_OR_FAIL(env);
     if (K < 0) return bad_arg("mgym_rollout: K < 0");
     if (!actions && e->n && K) return bad_arg("mgym_rollout: actions is NULL");
+    if (e->cfg.kind == MGYM_LUNARLANDER) {
+        // While the stream is being captured a LunarLander rollout records K steps, not its persistent launch: replays of a captured persistent
+        // launch ended in an abort inside the HIP runtime (35 of 40 fresh processes; eager launches of the same kernel and captured steps do not),
+        // unexplained at the end of round 4 — the per-environment results are the same words either way.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(e->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return e->Env::rollout(actions, K, obs_out, reward_out, done_out, trunc_out);
+    }
     return e->rollout(actions, K, obs_out, reward_out, done_out, trunc_out);
 }
 
